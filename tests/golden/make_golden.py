@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python for the hot path.
+
+Usage (build container only; the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py /root/reference
+
+What it does
+  * loads the reference's ``model/modules.py``, ``model/backbones/dit.py``, ``model/cfm.py``,
+    ``model/utils.py`` and ``durpred/*`` from ``<ref>/src`` *where they lie* (nothing is copied),
+    bypassing ``f5_tts/model/__init__.py`` (which drags in the trainer) by registering stub
+    parent packages with ``__path__`` set;
+  * injects ``sys.modules`` shims for third-party packages absent from this image
+    (x_transformers, torchdiffeq, torchaudio, librosa, numba, jieba, pypinyin).  The shims are
+    this repo's own restatements of those packages' *published* algorithms;
+    they are NOT reference code, and the arithmetic inside them stays "parity unpinned";
+  * runs seeded small configurations through the reference modules and stores inputs, weights
+    and outputs as ``.npz`` fixtures (data only) next to this script.
+
+The fixtures pin ``oracle/f5e_oracle.py`` (tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------- shims ----
+
+def _install_shims():
+    # x_transformers -------------------------------------------------------
+    class RotaryEmbedding(nn.Module):
+        def __init__(self, dim, theta=10000.0):
+            super().__init__()
+            inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2).float() / dim))
+            self.register_buffer("inv_freq", inv_freq)
+
+        def forward_from_seq_len(self, seq_len):
+            t = torch.arange(seq_len, device=self.inv_freq.device)
+            return self.forward(t)
+
+        def forward(self, t):
+            if t.ndim == 1:
+                t = t[None]
+            freqs = torch.einsum("b i , j -> b i j", t.type_as(self.inv_freq), self.inv_freq)
+            freqs = torch.stack((freqs, freqs), dim=-1).flatten(-2)
+            return freqs, 1.0
+
+    def rotate_half(x):
+        x = x.reshape(*x.shape[:-1], x.shape[-1] // 2, 2)
+        x1, x2 = x.unbind(dim=-1)
+        return torch.stack((-x2, x1), dim=-1).flatten(-2)
+
+    def apply_rotary_pos_emb(t, freqs, scale=1):
+        rot_dim, seq_len, orig_dtype = freqs.shape[-1], t.shape[-2], t.dtype
+        freqs = freqs[:, -seq_len:, :]
+        if t.ndim == 4 and freqs.ndim == 3:
+            freqs = freqs[:, None]
+        t, t_unrot = t[..., :rot_dim], t[..., rot_dim:]
+        t = (t * freqs.cos() * scale) + (rotate_half(t) * freqs.sin() * scale)
+        return torch.cat((t, t_unrot), dim=-1).type(orig_dtype)
+
+    class XRMSNorm(nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.scale = dim ** 0.5
+            self.g = nn.Parameter(torch.ones(dim))
+
+        def forward(self, x):
+            return F.normalize(x, dim=-1) * self.scale * self.g
+
+    xt = types.ModuleType("x_transformers")
+    xtx = types.ModuleType("x_transformers.x_transformers")
+    xtx.RotaryEmbedding = RotaryEmbedding
+    xtx.apply_rotary_pos_emb = apply_rotary_pos_emb
+    xt.RMSNorm = XRMSNorm
+    xt.x_transformers = xtx
+    sys.modules["x_transformers"] = xt
+    sys.modules["x_transformers.x_transformers"] = xtx
+
+    # torchdiffeq (fixed-grid euler / midpoint on the given grid) ----------
+    def odeint(fn, y0, t, method="euler", **kw):
+        ys, y = [y0], y0
+        for i in range(len(t) - 1):
+            t0, t1 = t[i], t[i + 1]
+            dt = t1 - t0
+            if method == "euler":
+                y = y + dt * fn(t0, y)
+            elif method == "midpoint":
+                half = 0.5 * dt
+                y = y + dt * fn(t0 + half, y + fn(t0, y) * half)
+            else:
+                raise NotImplementedError(method)
+            ys.append(y)
+        return torch.stack(ys)
+
+    td = types.ModuleType("torchdiffeq")
+    td.odeint = odeint
+    sys.modules["torchdiffeq"] = td
+
+    # torchaudio.transforms.MelSpectrogram (HTK, norm=None) ----------------
+    class MelSpectrogram(nn.Module):
+        def __init__(self, sample_rate, n_fft, win_length, hop_length, n_mels, power, center, normalized, norm):
+            super().__init__()
+            self.n_fft, self.win, self.hop, self.power, self.center = n_fft, win_length, hop_length, power, center
+            nf = n_fft // 2 + 1
+            all_freqs = torch.linspace(0, sample_rate // 2, nf)
+            m_max = 2595.0 * math.log10(1.0 + (sample_rate // 2) / 700.0)
+            m_pts = torch.linspace(0.0, m_max, n_mels + 2)
+            f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+            f_diff = f_pts[1:] - f_pts[:-1]
+            slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+            fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+            self.register_buffer("fb", fb)
+            self.register_buffer("window", torch.hann_window(win_length))
+
+        def forward(self, wav):
+            s = torch.stft(wav, self.n_fft, self.hop, self.win, self.window, center=self.center,
+                           pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+            if self.power != 1:
+                s = s.pow(self.power)
+            return torch.matmul(s.transpose(-1, -2), self.fb).transpose(-1, -2)
+
+    ta = types.ModuleType("torchaudio")
+    tat = types.ModuleType("torchaudio.transforms")
+    tat.MelSpectrogram = MelSpectrogram
+    ta.transforms = tat
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tat
+
+    # librosa.filters.mel (bigvgan path, never called here) ----------------
+    lb = types.ModuleType("librosa")
+    lbf = types.ModuleType("librosa.filters")
+    lbf.mel = lambda **kw: (_ for _ in ()).throw(NotImplementedError("librosa shim"))
+    lb.filters = lbf
+    sys.modules["librosa"] = lb
+    sys.modules["librosa.filters"] = lbf
+
+    # numba (training-only MAS jit): pass-through decorator ----------------
+    class _T:
+        def __getitem__(self, k):
+            return self
+
+        def __call__(self, *a, **k):
+            return self
+
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    nb.void = nb.int32 = nb.float32 = _T()
+    sys.modules["numba"] = nb
+
+    # tokeniser deps (not exercised) ---------------------------------------
+    jb = types.ModuleType("jieba")
+    jb.cut = lambda s: list(s)
+    sys.modules["jieba"] = jb
+    pp = types.ModuleType("pypinyin")
+    pp.Style = types.SimpleNamespace(TONE3=0)
+    pp.lazy_pinyin = lambda *a, **k: []
+    sys.modules["pypinyin"] = pp
+
+
+def load_reference(ref_root: str):
+    """Returns (modules_mod, dit_mod, cfm_mod, utils_mod) loaded from <ref_root>/src/f5_tts."""
+    src = os.path.join(ref_root, "src", "f5_tts")
+    if not os.path.isdir(src):
+        raise FileNotFoundError(src)
+    _install_shims()
+    for name, sub in (("f5_tts", ""), ("f5_tts.model", "model"), ("f5_tts.model.backbones", "model/backbones")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(src, sub)]
+        sys.modules[name] = pkg
+    # durpred's __init__ is importable as-is (einops present); let the normal machinery find it
+    mods = {}
+    for name in ("f5_tts.model.utils", "f5_tts.model.modules", "f5_tts.model.backbones.dit", "f5_tts.model.cfm"):
+        mods[name] = importlib.import_module(name)
+    return (mods["f5_tts.model.modules"], mods["f5_tts.model.backbones.dit"], mods["f5_tts.model.cfm"],
+            mods["f5_tts.model.utils"])
+
+
+# ------------------------------------------------------------- fixtures ----
+
+def _unzero(model: nn.Module, seed: int):
+    """a default-init DiT outputs exactly 0; re-randomise the zeroed tensors N(0, 0.02)."""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in model.named_parameters():
+        if float(p.detach().abs().max()) == 0.0:
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        if name.endswith("grn.gamma") or name.endswith("grn.beta"):
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    for name, b in model.named_buffers():
+        if name.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+        if name.endswith("running_var"):
+            b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+
+
+def _np(d):
+    out = {}
+    for k, v in d.items():
+        if v is None:
+            continue
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def _sd(model, prefix="w/"):
+    return {prefix + k: v for k, v in model.state_dict().items()}
+
+
+def make_dit_case(dit_mod, cfm_mod, tag, arch, b, n, nc, nt, steps, cfg_strength, seed, n_ppg=0,
+                  method="euler", mode="cfg"):
+    torch.manual_seed(seed)
+    ppg_config = dict(use_ppg=False)
+    if n_ppg:
+        ppg_config = dict(use_ppg=True, ppg_dim=32, use_transformer=False, transformer_config=dict(),
+                          combined_cond_drop_prob=[0.3, 0.1, 0.5, 0.1])
+    model = dit_mod.DiT(**arch, ppg_config=ppg_config)
+    _unzero(model, seed + 1)
+    model.eval()
+    g = torch.Generator().manual_seed(seed + 2)
+    x = torch.randn(b, n, arch["mel_dim"], generator=g)
+    cond = torch.randn(b, n, arch["mel_dim"], generator=g)
+    text = torch.randint(0, arch["text_num_embeds"], (b, nt), generator=g)
+    if b > 1:
+        text[1, nt - 3:] = -1
+    ppg = torch.randn(b, n_ppg, 32, generator=g) if n_ppg else None
+    tm = torch.tensor(0.37)
+    mask = None
+    if b > 1:
+        lens = torch.tensor([n] + [n - 7] * (b - 1))
+        mask = torch.arange(n)[None] < lens[:, None]
+    out = {}
+    # per-op intermediates through forward hooks on the first block
+    inter = {}
+
+    def hook(name):
+        def f(mod, inp, outp):
+            inter[name] = outp[0] if isinstance(outp, tuple) else outp
+        return f
+
+    hs = [model.transformer_blocks[0].register_forward_hook(hook("block0_out")),
+          model.input_embed.register_forward_hook(hook("input_embed_out")),
+          model.text_embed.register_forward_hook(hook("text_embed_out")),
+          model.time_embed.register_forward_hook(hook("time_embed_out")),
+          model.transformer_blocks[0].attn.register_forward_hook(hook("block0_attn_out"))]
+    if n_ppg:
+        hs.append(model.ppg_embed.register_forward_hook(hook("ppg_embed_out")))
+    with torch.no_grad():
+        pred_c = model.sample(x=x, cond=cond, text=text, ppg=ppg, time=tm, mask=mask,
+                              drop_audio_cond=False, drop_text=False, drop_ppg=False)
+        inter_c = dict(inter)
+        model.clear_cache()
+        pred_u = model.sample(x=x, cond=cond, text=text, ppg=ppg, time=tm, mask=mask,
+                              drop_audio_cond=True, drop_text=True, drop_ppg=True)
+        inter_u = dict(inter)
+        model.clear_cache()
+    for h in hs:
+        h.remove()
+    out.update({"fwd/x": x, "fwd/cond": cond, "fwd/text": text, "fwd/ppg": ppg, "fwd/time": tm, "fwd/mask": mask,
+                "fwd/pred_cond": pred_c, "fwd/pred_uncond": pred_u})
+    out.update({"fwd/c_" + k: v for k, v in inter_c.items()})
+    out.update({"fwd/u_" + k: v for k, v in inter_u.items()})
+
+    # full sampler through the reference CFM
+    cfm = cfm_mod.CFM(transformer=model, odeint_kwargs=dict(method=method), ppg_config=ppg_config,
+                      mel_spec_kwargs=dict(n_mel_channels=arch["mel_dim"]))
+    cfm.eval()
+    cond_mel = torch.randn(b, nc, arch["mel_dim"], generator=g)
+    lens_s = torch.tensor([nc] + [nc - 5] * (b - 1))
+    dur = torch.tensor([n] + [n - 7] * (b - 1))
+    with torch.no_grad():
+        if mode == "cfg":
+            o, traj = cfm.sample(cond=cond_mel, text=text, ppg=ppg, duration=dur, lens=lens_s, steps=steps,
+                                 cfg_strength=cfg_strength, sway_sampling_coef=-1.0, seed=seed + 3)
+        elif mode == "tts":
+            o, traj = cfm.sample_tts(cond=cond_mel, text=text, duration=dur, lens=lens_s, steps=steps,
+                                     alpha_spk=2.5, alpha_txt=3.0, sway_sampling_coef=-1.0, seed=seed + 3)
+        else:
+            o, traj = cfm.sample_vc(cond=cond_mel, ppg=ppg, duration=dur, lens=lens_s, steps=steps,
+                                    alpha_spk=2.5, alpha_ppg=3.0, sway_sampling_coef=-1.0, seed=seed + 3)
+    out.update({"smp/cond": cond_mel, "smp/lens": lens_s, "smp/duration": dur, "smp/out": o, "smp/traj": traj,
+                "smp/seed": seed + 3, "smp/steps": steps, "smp/cfg": cfg_strength})
+    out.update(_sd(model))
+    meta = dict(arch)
+    meta.update(b=b, n=n, nc=nc, nt=nt, n_ppg=n_ppg, mode=mode, method=method)
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, f"dit_{tag}.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_prep_case(cfm_mod, dit_mod):
+    """CFM.sample prep (masks/padding/duration clamp/y0/t grid) captured through a recording transformer."""
+    class Rec(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dim = 8
+            self.p = nn.Parameter(torch.zeros(1))
+            self.calls = []
+
+        def sample(self, **kw):
+            self.calls.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+            return torch.zeros_like(kw["x"])
+
+        def clear_cache(self):
+            pass
+
+    rec = Rec()
+    cfm = cfm_mod.CFM(transformer=rec, mel_spec_kwargs=dict(n_mel_channels=100))
+    g = torch.Generator().manual_seed(99)
+    wav = 0.1 * torch.randn(2, 256 * 11 + 17, generator=g)
+    text = torch.tensor([[5, 9, 2, -1, -1], [3, 3, 7, 7, 1]])
+    with torch.no_grad():
+        o, traj = cfm.sample(cond=wav, text=text, duration=torch.tensor([20, 30]), lens=torch.tensor([12, 9]),
+                             steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=11, max_duration=28)
+    c0 = rec.calls[0]
+    out = {"wav": wav, "text": text, "step_cond": c0["cond"], "mask": c0["mask"], "y0": traj[0],
+           "t": torch.stack([c["time"] for c in rec.calls[::2]]), "out": o,
+           "mel": cfm.mel_spec(wav)}
+    path = os.path.join(HERE, "cfm_prep.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path)
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    modules_mod, dit_mod, cfm_mod, utils_mod = load_reference(ref)
+    small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
+                 conv_layers=2)
+    make_dit_case(dit_mod, cfm_mod, "b1", small, b=1, n=48, nc=17, nt=9, steps=4, cfg_strength=2.0, seed=100)
+    make_dit_case(dit_mod, cfm_mod, "b2_mask", small, b=2, n=64, nc=21, nt=12, steps=3, cfg_strength=2.0, seed=200)
+    make_dit_case(dit_mod, cfm_mod, "b1_midpoint", small, b=1, n=40, nc=13, nt=7, steps=2, cfg_strength=1.5,
+                  seed=300, method="midpoint")
+    pe = dict(small, pe_attn_head=1, text_mask_padding=False, qk_norm="rms_norm", long_skip_connection=True)
+    make_dit_case(dit_mod, cfm_mod, "b2_ppg_tts", pe, b=2, n=48, nc=15, nt=10, steps=2, cfg_strength=2.0, seed=400,
+                  n_ppg=25, mode="tts")
+    make_dit_case(dit_mod, cfm_mod, "b1_ppg_vc", pe, b=1, n=40, nc=15, nt=10, steps=2, cfg_strength=2.0, seed=500,
+                  n_ppg=21, mode="vc")
+    make_prep_case(cfm_mod, dit_mod)
+
+
+if __name__ == "__main__":
+    main()

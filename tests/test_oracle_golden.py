@@ -1,0 +1,120 @@
+"""Pins oracle/f5e_oracle.py against fixtures produced by the reference itself (tests/golden/make_golden.py)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import f5e_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["b1", "b2_mask", "b1_midpoint", "b2_ppg_tts", "b1_ppg_vc"]
+TOL = dict(rtol=1e-4, atol=2e-5)  # fp32 vs fp32, same op order up to reassociation inside ATen
+
+
+def load_case(tag):
+    z = np.load(os.path.join(GOLD, f"dit_{tag}.npz"), allow_pickle=False)
+    meta = ast.literal_eval(str(z["meta"]))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    g = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("w/") and k != "meta"}
+    cfg = O.DiTConfig(dim=meta["dim"], depth=meta["depth"], heads=meta["heads"], dim_head=meta["dim_head"],
+                      ff_mult=meta["ff_mult"], mel_dim=meta["mel_dim"], text_num_embeds=meta["text_num_embeds"],
+                      text_dim=meta["text_dim"], text_mask_padding=meta.get("text_mask_padding", True),
+                      qk_norm=meta.get("qk_norm"), conv_layers=meta["conv_layers"],
+                      pe_attn_head=meta.get("pe_attn_head"),
+                      long_skip_connection=meta.get("long_skip_connection", False),
+                      use_ppg=meta["n_ppg"] > 0, ppg_dim=32)
+    return meta, sd, g, cfg
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_dit_forward_matches_reference(tag):
+    meta, sd, g, cfg = load_case(tag)
+    mask = g.get("fwd/mask")
+    ppg = g.get("fwd/ppg")
+    for drop, key in ((False, "fwd/pred_cond"), (True, "fwd/pred_uncond")):
+        pred = O.dit_sample(sd, cfg, g["fwd/x"], g["fwd/cond"], g["fwd/text"], ppg, g["fwd/time"],
+                            drop, drop, drop, mask)
+        torch.testing.assert_close(pred, g[key], **TOL)
+        assert float(g[key].abs().max()) > 1e-3  # not the vacuous all-zero network
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_dit_intermediates_match_reference(tag):
+    meta, sd, g, cfg = load_case(tag)
+    b, n = g["fwd/x"].shape[:2]
+    t = O.time_embedding(sd, g["fwd/time"].repeat(b))
+    torch.testing.assert_close(t, g["fwd/c_time_embed_out"], **TOL)
+    for drop, pre in ((False, "c_"), (True, "u_")):
+        te = O.text_embedding(sd, g["fwd/text"], b, n, drop, mask_padding=cfg.text_mask_padding)
+        torch.testing.assert_close(te, g[f"fwd/{pre}text_embed_out"], **TOL)
+        pe = None
+        if cfg.use_ppg:
+            pe = O.ppg_embedding(sd, g["fwd/ppg"], b, n, drop)
+            torch.testing.assert_close(pe, g[f"fwd/{pre}ppg_embed_out"], **TOL)
+        h = O.input_embedding(sd, g["fwd/x"], g["fwd/cond"], te, pe, drop)
+        torch.testing.assert_close(h, g[f"fwd/{pre}input_embed_out"], **TOL)
+        freqs = O.rope_freqs(n, cfg.dim_head, sd["rotary_embed.inv_freq"])
+        blk = O.dit_block(sd, "transformer_blocks.0.", h, t, cfg.heads, g.get("fwd/mask"), freqs, cfg.pe_attn_head)
+        torch.testing.assert_close(blk, g[f"fwd/{pre}block0_out"], **TOL)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_sampler_matches_reference(tag):
+    meta, sd, g, cfg = load_case(tag)
+    kw = dict(duration=g["smp/duration"], lens=g["smp/lens"], steps=int(g["smp/steps"]), sway_sampling_coef=-1.0,
+              seed=int(g["smp/seed"]), method=meta["method"])
+    if meta["mode"] == "cfg":
+        out, traj = O.cfm_sample(sd, cfg, g["smp/cond"], g["fwd/text"], g.get("fwd/ppg"),
+                                 cfg_strength=float(g["smp/cfg"]), **kw)
+    elif meta["mode"] == "tts":
+        out, traj = O.cfm_sample(sd, cfg, g["smp/cond"], g["fwd/text"], None, mode="tts", alpha_a=2.5, alpha_b=3.0, **kw)
+    else:
+        out, traj = O.cfm_sample(sd, cfg, g["smp/cond"], None, g["fwd/ppg"], mode="vc", alpha_a=2.5, alpha_b=3.0, **kw)
+    torch.testing.assert_close(traj[0], g["smp/traj"][0], rtol=0, atol=0)  # seeded noise: bit exact
+    torch.testing.assert_close(traj, g["smp/traj"], rtol=2e-4, atol=1e-4)
+    torch.testing.assert_close(out, g["smp/out"], rtol=2e-4, atol=1e-4)
+
+
+def test_sample_prep_matches_reference():
+    z = np.load(os.path.join(GOLD, "cfm_prep.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    mel = O.log_mel_spectrogram(g["wav"])
+    torch.testing.assert_close(mel, g["mel"], rtol=1e-5, atol=1e-5)
+    prep = O.sample_prep(mel.permute(0, 2, 1), g["text"], torch.tensor([20, 30]), torch.tensor([12, 9]), seed=11,
+                         max_duration=28)
+    torch.testing.assert_close(prep["step_cond"], g["step_cond"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(prep["mask"], g["mask"])
+    assert torch.equal(prep["y0"], g["y0"])
+    t = O.sway_time_grid(4, -1.0)
+    torch.testing.assert_close(t[:-1], g["t"], rtol=0, atol=0)
+    # closed form of the sway grid
+    i = torch.arange(5, dtype=torch.float64)
+    torch.testing.assert_close(t.double(), 1 - torch.cos(torch.pi * i / 8), rtol=0, atol=1e-6)
+
+
+def test_mel_and_istft_third_party_crosschecks():
+    """torchaudio / vocos arithmetic is 'parity unpinned'; cross-check structure with torch.stft/istft only."""
+    w = O.synthetic_ref_wave(20)
+    assert w.shape[-1] // 256 + 1 == 20
+    mel = O.log_mel_spectrogram(w)
+    assert mel.shape == (1, 100, 20)
+    fb = O.mel_filterbank_htk()
+    assert fb.shape == (513, 100) and float(fb.min()) >= 0 and float(fb.sum(0).min()) > 0
+    vs = O.init_vocos_state()
+    wav = O.vocos_decode(vs, mel)
+    assert wav.shape == (1, 256 * 19)
+    assert torch.isfinite(wav).all()
+
+
+def test_gumbel_vq_eval_shapes():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 16, generator=g)
+    w = torch.randn(2 * 10, 16, generator=g)
+    b = torch.zeros(20)
+    cb = torch.randn(1, 20, 8, generator=g)
+    q = O.gumbel_vq_eval(x, w, b, cb, groups=2, num_vars=10)
+    assert q.shape == (2, 5, 16)
+    k0 = (x[0, 0] @ w[:10].T).argmax()
+    torch.testing.assert_close(q[0, 0, :8], cb[0, k0])
