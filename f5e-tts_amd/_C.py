@@ -1,0 +1,92 @@
+"""ctypes binding of libf5e_hip.so (declared in include/f5e_abi.h).  Fails loudly: no fallback of any kind."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libf5e_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_MISH = range(6)
+
+_P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "f5e_abi_version": [],
+    "f5e_last_error": [],
+    "f5e_check_device": [],
+    "f5e_gemm_bf16_bias": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "f5e_gemm_bf16_gate_residual": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I],
+    "f5e_gemm_bf16_qkv_rope": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I],
+    "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
+    "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
+    "f5e_grn": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
+    "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I],
+    "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
+    "f5e_sinus_embed": [_P, _P, _P, _P, _I, _I, _F],
+    "f5e_rope_table": [_P, _P, _P, _I, _I],
+    "f5e_text_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_ode_update": [_P, _P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _LL],
+    "f5e_advance_eval": [_P, _P],
+    "f5e_stitch": [_P, _P, _P, _P, _P, _LL, _I],
+    "f5e_cast_bf16": [_P, _P, _P, _LL],
+    "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_dit_forward": [_P, _P],
+    "f5e_graph_begin": [_P],
+    "f5e_graph_end": [_P, C.POINTER(C.c_void_p)],
+    "f5e_graph_launch": [_P, _P],
+    "f5e_graph_destroy": [_P],
+}
+_RESTYPE = {"f5e_last_error": C.c_char_p}
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, _P) for n in ("w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2")]
+
+
+class DitPlan(C.Structure):
+    _fields_ = (
+        [(n, _I) for n in ("S", "B", "N", "n_pad", "D", "H", "rope_heads", "FF", "L", "mel", "mod_rows")]
+        + [("y", _P), ("w_x", _P), ("ldw_x", _I), ("in_const", _P)]
+        + [(n, _P) for n in ("convpos_w1", "convpos_b1", "convpos_w2", "convpos_b2", "rope_cs", "seq_len", "mod",
+                             "eval_ptr")]
+        + [("blocks", C.POINTER(BlockWeights)), ("w_proj", _P), ("b_proj", _P)]
+        + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
+    )
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is required (no CPU/PyTorch fallback exists). "
+                "Build it with `make -C f5e-tts_amd/csrc` or `__graft_entry__.build()`."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch, also loud
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        if handle.f5e_abi_version() != 1:
+            raise RuntimeError(f"libf5e_hip ABI version {handle.f5e_abi_version()} != 1")
+        _lib = handle
+    return _lib
+
+
+class F5EError(RuntimeError):
+    pass
+
+
+def check(rc: int, name: str) -> None:
+    if rc != 0:
+        msg = lib().f5e_last_error()
+        raise F5EError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

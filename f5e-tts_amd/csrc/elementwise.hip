@@ -1,0 +1,151 @@
+// Small HBM-bound elementwise kernels of the sampler (K2, K3 gather, K6, K14, K15 of SURVEY 2.3).
+#include "f5e_common.h"
+
+namespace {
+
+inline int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 2048 ? (g ? g : 1) : 2048);
+}
+
+// SinusPositionEmbedding (modules.py:149-161): out[e] = cat(sin(a), cos(a)), a = (scale * t[e]) * freqs[k],
+// freqs[k] = exp(-k * ln(1e4)/(half-1)) is a host-built constant table.
+__global__ void sinus_embed_kernel(const float* t, const float* freqs, float* out, int E, int dim, float scale) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * half) return;
+  const int e = i / half, k = i - e * half;
+  const float arg = (scale * t[e]) * freqs[k];
+  float s, c;
+  sincosf(arg, &s, &c);
+  out[(size_t)e * dim + k] = s;
+  out[(size_t)e * dim + half + k] = c;
+}
+
+// Rotary table (x_transformers RotaryEmbedding.forward_from_seq_len): out[n][i] = (cos, sin)(n * inv_freq[i])
+__global__ void rope_table_kernel(const float* inv_freq, float* out, int N, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, k = i - n * half;
+  const float ang = (float)n * inv_freq[k];
+  float s, c;
+  sincosf(ang, &s, &c);
+  out[(size_t)i * 2] = c;
+  out[(size_t)i * 2 + 1] = s;
+}
+
+// TextEmbedding front half (backbones/dit.py:68-80): out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]
+__global__ void text_gather_kernel(const int* ids, const float* table, const float* pos, const float* keep, float* out,
+                                   int B, int N, int TD, int max_pos) {
+  const int td4 = TD / 4;
+  const size_t total = (size_t)B * N * td4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % td4) * 4;
+    const size_t bn = i / td4;
+    const int n = (int)(bn % N);
+    f32x4 v = *(const f32x4*)(table + (size_t)ids[bn] * TD + c);
+    if (pos) v += *(const f32x4*)(pos + (size_t)min(n, max_pos - 1) * TD + c);
+    if (keep) v *= keep[bn];
+    *(f32x4*)(out + bn * TD + c) = v;
+  }
+}
+
+// CFG combination + fixed-grid ODE update (cfm.py:447, :187, :310; torchdiffeq euler/midpoint stage):
+//   v = mode 0: p0 | mode 1: p0 + (p0 - p1) * w0 | mode 2: w0 (p2 - p1) + w1 (p1 - p0) + p0
+//   dst = base + coef[eval] * v     (+ optional trajectory row)
+__global__ void ode_update_kernel(const float* pred, size_t branch_stride, int mode, float w0, float w1,
+                                  const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr,
+                                  size_t n) {
+  const float h = coef[eval_ptr ? *eval_ptr : 0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float p0 = pred[i];
+    float v = p0;
+    if (mode == 1) {
+      v = p0 + (p0 - pred[i + branch_stride]) * w0;
+    } else if (mode == 2) {
+      const float p1 = pred[i + branch_stride], p2 = pred[i + 2 * branch_stride];
+      v = w0 * (p2 - p1) + w1 * (p1 - p0) + p0;
+    }
+    const float y = base[i] + h * v;
+    dst[i] = y;
+    if (traj) traj[i] = y;
+  }
+}
+
+__global__ void advance_eval_kernel(int* eval_ptr) { *eval_ptr += 1; }
+
+// out = where(mask[b][n], cond, y)   (cfm.py:476)
+__global__ void stitch_kernel(const float* cond, const float* y, const unsigned char* mask, float* out, size_t rows,
+                              int C) {
+  const size_t total = rows * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+    out[i] = mask[i / C] ? cond[i] : y[i];
+}
+
+__global__ void cast_bf16_kernel(const float* x, bf16* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (bf16)x[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int f5e_sinus_embed(hipStream_t st, const float* t, const float* freqs, float* out, int E, int dim, float scale) {
+  F5E_REQUIRE(t && freqs && out && E > 0 && dim >= 4 && dim % 2 == 0, "sinus_embed: bad arguments");
+  const int total = E * dim / 2;
+  hipLaunchKernelGGL(sinus_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, st, t, freqs, out, E, dim, scale);
+  F5E_LAUNCH_CHECK("sinus_embed");
+  return F5E_OK;
+}
+
+int f5e_rope_table(hipStream_t st, const float* inv_freq, float* out, int N, int half) {
+  F5E_REQUIRE(inv_freq && out && N > 0 && half > 0, "rope_table: bad arguments");
+  const int total = N * half;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((total + 255) / 256), dim3(256), 0, st, inv_freq, out, N, half);
+  F5E_LAUNCH_CHECK("rope_table");
+  return F5E_OK;
+}
+
+int f5e_text_gather(hipStream_t st, const int* ids, const float* table, const float* pos, const float* keep,
+                    float* out, int B, int N, int TD, int max_pos) {
+  F5E_REQUIRE(ids && table && out && B > 0 && N > 0 && TD > 0 && TD % 4 == 0, "text_gather: bad arguments");
+  hipLaunchKernelGGL(text_gather_kernel, dim3(grid_for((size_t)B * N * TD / 4)), dim3(256), 0, st, ids, table, pos,
+                     keep, out, B, N, TD, max_pos);
+  F5E_LAUNCH_CHECK("text_gather");
+  return F5E_OK;
+}
+
+int f5e_ode_update(hipStream_t st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+                   const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr, long long n) {
+  F5E_REQUIRE(pred && base && dst && coef && n > 0, "ode_update: bad arguments");
+  F5E_REQUIRE(mode >= 0 && mode <= 2, "ode_update: mode must be 0 (plain), 1 (cfg) or 2 (three-branch)");
+  hipLaunchKernelGGL(ode_update_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, pred, (size_t)branch_stride, mode,
+                     w0, w1, base, dst, traj, coef, eval_ptr, (size_t)n);
+  F5E_LAUNCH_CHECK("ode_update");
+  return F5E_OK;
+}
+
+int f5e_advance_eval(hipStream_t st, int* eval_ptr) {
+  F5E_REQUIRE(eval_ptr, "advance_eval: null");
+  hipLaunchKernelGGL(advance_eval_kernel, dim3(1), dim3(1), 0, st, eval_ptr);
+  F5E_LAUNCH_CHECK("advance_eval");
+  return F5E_OK;
+}
+
+int f5e_stitch(hipStream_t st, const float* cond, const float* y, const unsigned char* mask, float* out,
+               long long rows, int C) {
+  F5E_REQUIRE(cond && y && mask && out && rows > 0 && C > 0, "stitch: bad arguments");
+  hipLaunchKernelGGL(stitch_kernel, dim3(grid_for((size_t)rows * C)), dim3(256), 0, st, cond, y, mask, out,
+                     (size_t)rows, C);
+  F5E_LAUNCH_CHECK("stitch");
+  return F5E_OK;
+}
+
+int f5e_cast_bf16(hipStream_t st, const float* x, void* y, long long n) {
+  F5E_REQUIRE(x && y && n > 0, "cast_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, x, (bf16*)y, (size_t)n);
+  F5E_LAUNCH_CHECK("cast_bf16");
+  return F5E_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// bf16 MFMA GEMM with fused epilogues for the DiT block linears (K8/K11/K12/K13 of SURVEY 2.3).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]      A: activations [M][K] bf16, W: nn.Linear weight [N][K] bf16
+//
+// Replaces the F.linear calls at reference model/modules.py:452-454 (to_q/k/v), :495 (to_out),
+// :349-350 (FeedForward) and backbones/dit.py:470 (proj_out), each fused with what follows it.
+//
+// gfx950 design notes
+//   * 256 threads = 4 waves (2x2); block tile BM x BN, K-step 64; v_mfma_f32_16x16x32_bf16.
+//   * operands are SWAPPED (W rows feed the MFMA "A" port, activation rows the "B" port) so an
+//     accumulator register quad holds 4 CONSECUTIVE output columns n for one row m: bias / gate /
+//     RoPE pairs are lane-local, bf16 stores are 8 B and fp32 residual updates 16 B per lane.
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4), 2 LDS stages, one barrier per K-step.
+//     The LDS image is lane-linear; the bank swizzle (16-B chunk ^ ((row>>1)&7)) is applied to the
+//     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
+//     16-lane ds_read_b128 groups are conflict free.
+#include "f5e_common.h"
+
+namespace {
+
+struct GemmArgs {
+  const bf16* A; int lda;
+  const bf16* W; int ldw;
+  const float* bias;
+  int M, N, K;
+  void* out; int ldo;
+  // gate + residual epilogue
+  float* resid; int ldr;
+  const float* gate; int gate_stride; int gate_rows;
+  const int* eval_ptr; int eval_stride;
+  int rows_per_seq;
+  const int* seq_len;
+  // qkv + rope epilogue
+  bf16* q; bf16* k; bf16* vt;
+  int n_pad; int heads; int rope_heads;
+  const float* cos_sin;  // [rows_per_seq][32][2]
+  int tiles_m, tiles_n;
+};
+
+enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr int BK = 64;
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int W_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + W_BYTES;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int tile_n = bid / a.tiles_m;
+  const int tile_m = bid - tile_n * a.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging: chunk i (16 B) of a [rows][64] bf16 tile sits at LDS byte i*16 ----
+  // source chunk for LDS position (row, c) is c ^ ((row>>1)&7)
+  constexpr int A_IT = BM * 8 / 256;
+  constexpr int W_IT = BN * 8 / 256;
+  const bf16* a_src[A_IT];
+  const bf16* w_src[W_IT];
+#pragma unroll
+  for (int j = 0; j < A_IT; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+    const int gr = min(m0 + row, a.M - 1);
+    a_src[j] = a.A + (size_t)gr * a.lda + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < W_IT; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+    const int gr = min(n0 + row, a.N - 1);
+    w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + 256 * j) * 16);
+#pragma unroll
+    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + 256 * j) * 16);
+  };
+
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = a.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage(buf ^ 1, kt + 1);
+    const char* As = smem + buf * STAGE;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 xf[TM], wf[TN];
+      const int c = kk * 4 + fq;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm0 + j * 16 + fr;
+        xf[j] = *(const bf16x8*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn0 + i * 16 + fr;
+        wf[i] = *(const bf16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] = C[m = m0+wm0+16j+fr][n = n0+wn0+16i+4fq+r] ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm0 + j * 16 + fr;
+    if (m >= a.M) continue;
+    int seq = 0, pos = m;
+    if (EPI == EPI_GATE_RES || EPI == EPI_QKV_ROPE) {
+      seq = m / a.rows_per_seq;
+      pos = m - seq * a.rows_per_seq;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn0 + i * 16 + fq * 4;
+      if (n >= a.N) continue;
+      f32x4 v = acc[i][j];
+      if (a.bias) {
+        const f32x4 b = *(const f32x4*)(a.bias + n);
+        v += b;
+      }
+      if (EPI == EPI_BF16) {
+        *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + n) = f2bf4(v[0], v[1], v[2], v[3]);
+      } else if (EPI == EPI_BF16_GELU) {
+        *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + n) =
+            f2bf4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+      } else if (EPI == EPI_F32) {
+        *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
+      } else if (EPI == EPI_GATE_RES) {
+        const bool live = (a.seq_len == nullptr) || (pos < a.seq_len[seq]);
+        if (live) {
+          const size_t eoff = a.eval_ptr ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
+          const f32x4 g = *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n);
+          float* xp = a.resid + (size_t)m * a.ldr + n;
+          f32x4 x = *(const f32x4*)xp;
+          x += g * v;
+          *(f32x4*)xp = x;
+        }
+      } else if (EPI == EPI_QKV_ROPE) {
+        const int inner = a.heads * 64;
+        const int which = n / inner;
+        const int nn = n - which * inner;
+        const int head = nn >> 6, d = nn & 63;
+        if (which < 2 && head < a.rope_heads) {
+          const f32x4 cs = *(const f32x4*)(a.cos_sin + ((size_t)pos * 32 + (d >> 1)) * 2);
+          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+          v[0] = x0 * cs[0] - x1 * cs[1];
+          v[1] = x1 * cs[0] + x0 * cs[1];
+          v[2] = x2 * cs[2] - x3 * cs[3];
+          v[3] = x3 * cs[2] + x2 * cs[3];
+        }
+        const size_t sh = (size_t)seq * a.heads + head;
+        if (which < 2) {
+          bf16* dst = (which == 0 ? a.q : a.k) + (sh * a.n_pad + pos) * 64 + d;
+          *(bf16x4*)dst = f2bf4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16* dst = a.vt + (sh * 64 + d) * a.n_pad + pos;
+          dst[0] = (bf16)v[0];
+          dst[(size_t)a.n_pad] = (bf16)v[1];
+          dst[(size_t)2 * a.n_pad] = (bf16)v[2];
+          dst[(size_t)3 * a.n_pad] = (bf16)v[3];
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int EPI>
+int launch(GemmArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const int grid = a.tiles_m * a.tiles_n;
+  constexpr int lds = 2 * (BM + BN) * 64 * 2;
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, st, a);
+  F5E_LAUNCH_CHECK("gemm_bf16");
+  return F5E_OK;
+}
+
+template <int EPI>
+int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
+  // Tile choice: the largest tile that still gives >= ~1 block per CU (256 CUs); tile_hint overrides (tests/tuning).
+  auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  int sel = tile_hint;
+  if (sel <= 0) {
+    if (blocks(128, 128) >= 224) sel = 1;
+    else if (blocks(128, 64) >= 224 && EPI != EPI_QKV_ROPE) sel = 2;
+    else sel = 3;
+  }
+  switch (sel) {
+    case 1: return launch<128, 128, EPI>(a, st);
+    case 2: return launch<128, 64, EPI>(a, st);
+    default: return launch<64, 64, EPI>(a, st);
+  }
+}
+
+int check_common(const GemmArgs& a) {
+  F5E_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  F5E_REQUIRE(a.K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a.K);
+  F5E_REQUIRE(a.N % 4 == 0, "gemm_bf16: N=%d must be a multiple of 4", a.N);
+  F5E_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm_bf16: lda/ldw must be multiples of 8 elements");
+  F5E_REQUIRE(a.A && a.W, "gemm_bf16: null operand");
+  return F5E_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f5e_gemm_bf16_bias(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                       int ldo, int M, int N, int K, int act, int out_f32, int tile_hint) {
+  GemmArgs a{};
+  a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
+  if (int e = check_common(a)) return e;
+  F5E_REQUIRE(out && ldo % 4 == 0, "gemm_bf16_bias: bad output");
+  if (out_f32) {
+    F5E_REQUIRE(act == F5E_ACT_NONE, "gemm_bf16_bias: f32 output supports no activation");
+    return dispatch<EPI_F32>(a, st, tile_hint);
+  }
+  if (act == F5E_ACT_GELU_TANH) return dispatch<EPI_BF16_GELU>(a, st, tile_hint);
+  F5E_REQUIRE(act == F5E_ACT_NONE, "gemm_bf16_bias: unsupported activation %d", act);
+  return dispatch<EPI_BF16>(a, st, tile_hint);
+}
+
+int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                int N, int K, int tile_hint) {
+  GemmArgs a{};
+  a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
+  a.M = M; a.N = N; a.K = K;
+  a.resid = resid; a.ldr = ldr; a.gate = gate; a.gate_stride = gate_stride; a.gate_rows = gate_rows;
+  a.rows_per_seq = rows_per_seq; a.seq_len = seq_len; a.eval_ptr = eval_ptr; a.eval_stride = eval_stride;
+  if (int e = check_common(a)) return e;
+  F5E_REQUIRE(resid && gate && ldr % 4 == 0 && gate_stride % 4 == 0 && gate_rows > 0 && rows_per_seq > 0,
+              "gemm_bf16_gate_residual: bad residual/gate arguments");
+  return dispatch<EPI_GATE_RES>(a, st, tile_hint);
+}
+
+int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
+                           void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                           int rows_per_seq, int M, int K, int tile_hint) {
+  GemmArgs a{};
+  a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
+  a.M = M; a.N = 3 * heads * 64; a.K = K;
+  a.q = (bf16*)q; a.k = (bf16*)k; a.vt = (bf16*)vt; a.n_pad = n_pad; a.heads = heads; a.rope_heads = rope_heads;
+  a.cos_sin = cos_sin; a.rows_per_seq = rows_per_seq;
+  if (int e = check_common(a)) return e;
+  F5E_REQUIRE(q && k && vt && cos_sin, "gemm_bf16_qkv_rope: null output/table");
+  F5E_REQUIRE(heads > 0 && rope_heads >= 0 && rope_heads <= heads, "gemm_bf16_qkv_rope: bad head counts");
+  F5E_REQUIRE(rows_per_seq > 0 && n_pad >= rows_per_seq && n_pad % 64 == 0,
+              "gemm_bf16_qkv_rope: n_pad=%d must be a multiple of 64 and >= rows_per_seq=%d", n_pad, rows_per_seq);
+  return dispatch<EPI_QKV_ROPE>(a, st, tile_hint);
+}
+
+}  // extern "C"

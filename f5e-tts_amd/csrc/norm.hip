@@ -1,0 +1,145 @@
+// LayerNorm family (K7/K12/K13 of SURVEY 2.3) and GRN (K3). All HBM-bound: one wave per row, fp32 statistics.
+//
+// f5e_layernorm: y = LN(x; eps, no affine) [* gamma + beta] [* (1 + scale[seq]) + shift[seq]]
+//   - AdaLayerNorm / ff_norm modulate / AdaLayerNorm_Final: reference model/modules.py:301-336, :637
+//   - affine LN of ConvNeXtV2Block (modules.py:253,264) and of the Vocos backbone
+// Statistics follow F.layer_norm: mean, then biased variance of the centred values (two passes in registers).
+#include "f5e_common.h"
+
+namespace {
+
+struct LnArgs {
+  const float* x; int ldx;
+  void* y; int ldy; int y_bf16;
+  const float* gamma; const float* beta;      // [D] or null
+  const float* scale; const float* shift;     // [mod_rows][mod_stride] or null
+  int mod_stride, mod_rows, rows_per_seq;
+  int rows, D;
+  float eps;
+  const int* eval_ptr; int eval_stride;       // tables advance by eval_stride floats per ODE evaluation
+};
+
+template <int VPL>  // float4 vectors per lane: D = VPL * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* xp = a.x + (size_t)row * a.ldx;
+  f32x4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *(const f32x4*)(xp + (i * 64 + lane) * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)a.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] -= mean;
+    ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)a.D + a.eps);
+  const int mrow = a.scale ? (row / a.rows_per_seq) % a.mod_rows : 0;
+  const size_t eoff = (a.scale && a.eval_ptr) ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    f32x4 y = v[i] * rstd;
+    if (a.gamma) y = y * *(const f32x4*)(a.gamma + c) + *(const f32x4*)(a.beta + c);
+    if (a.scale) {
+      const f32x4 sc = *(const f32x4*)(a.scale + eoff + (size_t)mrow * a.mod_stride + c);
+      const f32x4 sh = *(const f32x4*)(a.shift + eoff + (size_t)mrow * a.mod_stride + c);
+      y = y * (1.0f + sc) + sh;
+    }
+    if (a.y_bf16)
+      *(bf16x4*)((bf16*)a.y + (size_t)row * a.ldy + c) = f2bf4(y[0], y[1], y[2], y[3]);
+    else
+      *(f32x4*)((float*)a.y + (size_t)row * a.ldy + c) = y;
+  }
+}
+
+// GRN pass 1: gx[b][c] = sqrt(sum_t x[b][t][c]^2)   x: [B][T][C] fp32
+__global__ __launch_bounds__(256) void grn_norm_kernel(const float* x, float* gx, int T, int C) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int t = w; t < T; t += 4) {
+      const float v = x[((size_t)b * T + t) * C + c];
+      s += v * v;
+    }
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x;
+    gx[(size_t)b * C + c] = sqrtf((red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
+  }
+}
+
+// GRN pass 2: y = gamma * (x * gx / (mean_c gx + 1e-6)) + beta + x        (modules.py:231-234)
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* x, const float* gx, const float* gamma,
+                                                        const float* beta, float* y, int T, int C) {
+  __shared__ float s_mean;
+  const int b = blockIdx.y;
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) s += gx[(size_t)b * C + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) s_mean = s / (float)C;
+  }
+  __syncthreads();
+  const float inv = 1.0f / (s_mean + 1e-6f);
+  const size_t total = (size_t)T * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float v = x[(size_t)b * total + i];
+    y[(size_t)b * total + i] = gamma[c] * (v * (gx[(size_t)b * C + c] * inv)) + beta[c] + v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* gamma,
+                  const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
+                  int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps) {
+  F5E_REQUIRE(x && y && rows > 0, "layernorm: null/empty");
+  F5E_REQUIRE(D % 256 == 0 && D >= 256 && D <= 2048, "layernorm: D=%d must be a multiple of 256 in [256, 2048]", D);
+  F5E_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: ldx/ldy must be multiples of 4");
+  F5E_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm: gamma and beta go together");
+  F5E_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm: scale and shift go together");
+  if (scale) F5E_REQUIRE(mod_rows > 0 && rows_per_seq > 0 && mod_stride % 4 == 0, "layernorm: bad modulation table");
+  LnArgs a{x, ldx, y, ldy, y_bf16, gamma, beta, scale, shift, mod_stride, mod_rows, rows_per_seq, rows, D, eps,
+           eval_ptr, eval_stride};
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL(layernorm_kernel<7>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, a); break;
+  }
+  F5E_LAUNCH_CHECK("layernorm");
+  return F5E_OK;
+}
+
+int f5e_grn(hipStream_t st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B,
+            int T, int C) {
+  F5E_REQUIRE(x && y && gx_ws && gamma && beta && B > 0 && T > 0 && C > 0, "grn: null/empty");
+  hipLaunchKernelGGL(grn_norm_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, gx_ws, T, C);
+  F5E_LAUNCH_CHECK("grn_norm");
+  const size_t total = (size_t)T * C;
+  const int gx = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(grn_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, gx_ws, gamma, beta, y, T, C);
+  F5E_LAUNCH_CHECK("grn_apply");
+  return F5E_OK;
+}
+
+}  // extern "C"

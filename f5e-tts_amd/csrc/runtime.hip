@@ -1,0 +1,122 @@
+// ABI plumbing (version, thread-local errors, device check), hipGraph capture helpers and the fused DiT evaluation
+// that chains the per-op kernels for one network call (reference backbones/dit.py:452-470, model/modules.py:627-641).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "f5e_common.h"
+
+static thread_local char g_err[512] = "";
+
+void f5e_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define HIP_TRY(call, what)                                                        \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      f5e_set_error("%s: %s", what, hipGetErrorString(e_));                        \
+      return F5E_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define F5E_TRY(call)        \
+  do {                       \
+    int r_ = (call);         \
+    if (r_ != F5E_OK) return r_; \
+  } while (0)
+
+extern "C" {
+
+int f5e_abi_version(void) { return F5E_ABI_VERSION; }
+const char* f5e_last_error(void) { return g_err; }
+
+int f5e_check_device(void) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    f5e_set_error("libf5e_hip is built for gfx950 only; device %d is %s", dev, prop.gcnArchName);
+    return F5E_ERR_UNSUPPORTED;
+  }
+  return F5E_OK;
+}
+
+int f5e_graph_begin(hipStream_t st) {
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+  return F5E_OK;
+}
+
+int f5e_graph_end(hipStream_t st, void** graph_exec_out) {
+  F5E_REQUIRE(graph_exec_out, "graph_end: null output");
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture(st, &g), "hipStreamEndCapture");
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    f5e_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return F5E_ERR_HIP;
+  }
+  *graph_exec_out = (void*)ex;
+  return F5E_OK;
+}
+
+int f5e_graph_launch(void* graph_exec, hipStream_t st) {
+  F5E_REQUIRE(graph_exec, "graph_launch: null graph");
+  HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, st), "hipGraphLaunch");
+  return F5E_OK;
+}
+
+int f5e_graph_destroy(void* graph_exec) {
+  if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec), "hipGraphExecDestroy");
+  return F5E_OK;
+}
+
+int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
+  F5E_REQUIRE(p, "dit_forward: null plan");
+  F5E_REQUIRE(p->S > 0 && p->B > 0 && p->S % p->B == 0 && p->N > 0 && p->L > 0, "dit_forward: bad S/B/N/L");
+  F5E_REQUIRE(p->D % 256 == 0 && p->H > 0 && p->FF % 64 == 0 && p->mel % 4 == 0, "dit_forward: unsupported dims");
+  F5E_REQUIRE(p->y && p->w_x && p->in_const && p->rope_cs && p->mod && p->blocks && p->w_proj, "dit_forward: null input");
+  F5E_REQUIRE(p->h0 && p->h0_bf16 && p->c1 && p->x && p->hn && p->q && p->k && p->vt && p->ao && p->ff && p->pred,
+              "dit_forward: null workspace");
+  const int M = p->S * p->N, D = p->D, inner = p->H * 64;
+  const int row_stride = p->L * 6 * D + 2 * D;
+  const int eval_stride = p->mod_rows * row_stride;
+
+  // K4: input projection, x-part per step + hoisted cond/text/ppg part (backbones/dit.py:173-175)
+  F5E_TRY(f5e_gemm_f32(st, p->y, p->mel, p->B * p->N, F5E_ACT_NONE, p->w_x, p->ldw_x, nullptr, F5E_ACT_NONE, nullptr,
+                       p->in_const, D, M, nullptr, p->h0, D, p->h0_bf16, D, M, D, p->mel));
+  // K5: conv position embedding + residual (dit.py:176)
+  F5E_TRY(f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D));
+  F5E_TRY(f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D));
+
+  for (int l = 0; l < p->L; ++l) {
+    const f5e_dit_block_weights& w = p->blocks[l];
+    const float* mb = p->mod + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + D, mb, row_stride, p->mod_rows, p->N,
+                          p->eval_ptr, eval_stride, M, D, 1e-6f));
+    F5E_TRY(f5e_gemm_bf16_qkv_rope(st, p->hn, D, w.w_qkv, D, w.b_qkv, p->q, p->k, p->vt, p->n_pad, p->H, p->rope_heads,
+                                   p->rope_cs, p->N, M, D, 0));
+    F5E_TRY(f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
+    F5E_TRY(f5e_gemm_bf16_gate_residual(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D, row_stride,
+                                        p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D, inner, 0));
+    F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + 4 * D, mb + 3 * D, row_stride, p->mod_rows,
+                          p->N, p->eval_ptr, eval_stride, M, D, 1e-6f));
+    F5E_TRY(f5e_gemm_bf16_bias(st, p->hn, D, w.w_ff1, D, w.b_ff1, p->ff, p->FF, M, p->FF, D, F5E_ACT_GELU_TANH, 0, 0));
+    F5E_TRY(f5e_gemm_bf16_gate_residual(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D, row_stride,
+                                        p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF, 0));
+  }
+  // K13: final AdaLN (scale, shift order: modules.py:333) + proj_out
+  const float* mf = p->mod + (size_t)p->L * 6 * D;
+  F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mf, mf + D, row_stride, p->mod_rows, p->N,
+                        p->eval_ptr, eval_stride, M, D, 1e-6f));
+  F5E_TRY(f5e_gemm_bf16_bias(st, p->hn, D, p->w_proj, D, p->b_proj, p->pred, p->mel, M, p->mel, D, F5E_ACT_NONE, 1, 0));
+  return F5E_OK;
+}
+
+}  // extern "C"

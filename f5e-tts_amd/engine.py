@@ -1,0 +1,418 @@
+"""Host-side engine of the hot path: weight repack, workspace planning, once-per-call embeddings/tables and the
+hipGraph-driven ODE loop.  All arithmetic is done by libf5e_hip.so (``ops``); torch is used for device memory,
+integer/bool index preparation and streams only.
+
+Mirrors, at the level of *what is computed*: DiT.sample (reference backbones/dit.py:417-472) and the loop body of
+CFM.sample / sample_tts / sample_vc (model/cfm.py:430-471), restructured for MI355X:
+  * the CFG branches of one step are batched into ONE S = branches*B forward (weights stream once per step);
+  * everything that depends only on t (time MLP, 22 AdaLN tables, final AdaLN) is built for the whole time grid before
+    the loop; everything that depends only on (cond, text, ppg) (text/PPG embeddings, their share of the input
+    projection) once per call and branch -- the reference recomputes the PPG embedding every forward (dit.py:448);
+  * one ODE step (network + CFG + Euler/midpoint update) is captured as a hipGraph and replayed; per-step scalars come
+    from device tables indexed by a device-side evaluation counter.
+"""
+from __future__ import annotations
+
+import math
+import threading
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _C, ops
+
+Tensor = torch.Tensor
+BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+@dataclass
+class DiTConfig:
+    dim: int = 1024
+    depth: int = 22
+    heads: int = 16
+    dim_head: int = 64
+    ff_mult: int = 2
+    mel_dim: int = 100
+    text_num_embeds: int = 2545
+    text_dim: int = 512
+    text_mask_padding: bool = True
+    qk_norm: Optional[str] = None
+    conv_layers: int = 4
+    pe_attn_head: Optional[int] = None
+    long_skip_connection: bool = False
+    use_ppg: bool = False
+    ppg_dim: int = 256
+
+    def validate(self) -> None:
+        if self.dim_head != 64:
+            raise _C.F5EError("HIP path is built for dim_head = 64")
+        if self.dim % 256 or self.text_dim % 256:
+            raise _C.F5EError(f"HIP path needs dim and text_dim to be multiples of 256 (got {self.dim}, {self.text_dim})")
+        if (self.dim // 16) != 64:
+            raise _C.F5EError("ConvPositionEmbedding kernel is built for 64 channels per group (dim = 1024 with "
+                              f"groups = 16); got dim = {self.dim}")
+        if self.qk_norm is not None:
+            raise _C.F5EError("qk_norm is not on the F5TTS_v1_Base path and is not built yet")
+        if self.long_skip_connection:
+            raise _C.F5EError("long_skip_connection is not on the F5TTS_v1_Base path and is not built yet")
+        if self.mel_dim % 4:
+            raise _C.F5EError("mel_dim must be a multiple of 4")
+
+
+def fft_tables(device) -> Tuple[Tensor, Tensor]:
+    """hann window (periodic, as torch.hann_window) and 1024-point twiddles (cos, -sin), built in float64."""
+    k = torch.arange(512, dtype=torch.float64)
+    tw = torch.stack((torch.cos(2 * math.pi * k / 1024), -torch.sin(2 * math.pi * k / 1024)), -1).float()
+    return torch.hann_window(1024).to(device), tw.to(device).contiguous()
+
+
+def mel_filterbank(n_freqs: int, n_mels: int, sr: int) -> Tensor:
+    """HTK triangular filterbank, norm=None (torchaudio.functional.melscale_fbanks) -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sr // 2, n_freqs)
+    m_max = 2595.0 * math.log10(1.0 + (sr // 2) / 700.0)
+    m_pts = torch.linspace(0.0, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0).contiguous()
+
+
+def text_pos_table(dim: int, end: int = 4096, theta: float = 10000.0) -> Tensor:
+    """precompute_freqs_cis (model/modules.py:196-207): constant [end, dim] = cos || sin table."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    ang = torch.outer(torch.arange(end), freqs).float()
+    return torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+
+
+class DiTEngine:
+    """Device-resident, repacked weights of one DiT + the code that runs it through the C ABI."""
+
+    def __init__(self, sd: Dict[str, Tensor], cfg: DiTConfig, device):
+        cfg.validate()
+        ops.require_device()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        dv = self.device
+        f = lambda k: sd[k].detach().to(dv, F32).contiguous()  # noqa: E731
+        D, L = cfg.dim, cfg.depth
+        self.L = L
+        self.inner = cfg.heads * 64
+        self.FF = D * cfg.ff_mult
+        # --- once-per-call fp32 weights
+        self.tm_w0, self.tm_b0 = f("time_embed.time_mlp.0.weight"), f("time_embed.time_mlp.0.bias")
+        self.tm_w2, self.tm_b2 = f("time_embed.time_mlp.2.weight"), f("time_embed.time_mlp.2.bias")
+        half = 128
+        self.sinus_freqs = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1))).to(dv)
+        self.text_table = f("text_embed.text_embed.weight")
+        self.text_blocks = []
+        for i in range(cfg.conv_layers):
+            p = f"text_embed.text_blocks.{i}."
+            self.text_blocks.append(dict(
+                dw_w=f(p + "dwconv.weight")[:, 0, :].t().contiguous(), dw_b=f(p + "dwconv.bias"),
+                ln_g=f(p + "norm.weight"), ln_b=f(p + "norm.bias"),
+                w1=f(p + "pwconv1.weight"), b1=f(p + "pwconv1.bias"),
+                grn_g=f(p + "grn.gamma").view(-1).contiguous(), grn_b=f(p + "grn.beta").view(-1).contiguous(),
+                w2=f(p + "pwconv2.weight"), b2=f(p + "pwconv2.bias")))
+        self.text_pos = text_pos_table(cfg.text_dim).to(dv) if cfg.conv_layers > 0 else None
+        self.in_w, self.in_b = f("input_embed.proj.weight"), f("input_embed.proj.bias")
+        self.ppg = None
+        if cfg.use_ppg:
+            pp = "ppg_embed.ppg_proj."
+            convs = []
+            for ci, bi in ((2, 3), (6, 7), (10, 11)):
+                w, b = f(pp + f"{ci}.weight"), f(pp + f"{ci}.bias")
+                g, be = f(pp + f"{bi}.weight"), f(pp + f"{bi}.bias")
+                mu, var = f(pp + f"{bi}.running_mean"), f(pp + f"{bi}.running_var")
+                s = g / torch.sqrt(var + 1e-5)  # eval-mode BatchNorm1d folded into the conv (weights-only transform)
+                wf = (w * s[:, None, None]).permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()  # [oc][k*ic]
+                convs.append((wf, ((b - mu) * s + be).contiguous()))
+            self.ppg = dict(w0=f(pp + "0.weight"), b0=f(pp + "0.bias"), convs=convs,
+                            w15=f(pp + "15.weight"), b15=f(pp + "15.bias"))
+        # conv position embedding: [D][64][31] -> [G][tap][oc][ic] bf16
+        G = D // 64
+        self.cp = []
+        for j in (0, 2):
+            w = f(f"input_embed.conv_pos_embed.conv1d.{j}.weight")
+            self.cp.append((w.view(G, 64, 64, 31).permute(0, 3, 1, 2).contiguous().to(BF),
+                            f(f"input_embed.conv_pos_embed.conv1d.{j}.bias")))
+        inv = sd.get("rotary_embed.inv_freq")
+        self.inv_freq = (inv.detach().float() if inv is not None
+                         else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
+        # --- per-block weights: AdaLN linears stay fp32 (tables), the four block linears go bf16
+        self.adaln = []
+        self.blocks_keep = []
+        self.block_arr = (_C.BlockWeights * L)()
+        for i in range(L):
+            p = f"transformer_blocks.{i}."
+            self.adaln.append((f(p + "attn_norm.linear.weight"), f(p + "attn_norm.linear.bias")))
+            w_qkv = torch.cat([f(p + "attn.to_q.weight"), f(p + "attn.to_k.weight"), f(p + "attn.to_v.weight")], 0).to(BF)
+            b_qkv = torch.cat([f(p + "attn.to_q.bias"), f(p + "attn.to_k.bias"), f(p + "attn.to_v.bias")], 0)
+            w_out, b_out = f(p + "attn.to_out.0.weight").to(BF), f(p + "attn.to_out.0.bias")
+            w_ff1, b_ff1 = f(p + "ff.ff.0.0.weight").to(BF), f(p + "ff.ff.0.0.bias")
+            w_ff2, b_ff2 = f(p + "ff.ff.2.weight").to(BF), f(p + "ff.ff.2.bias")
+            keep = (w_qkv, b_qkv, w_out, b_out, w_ff1, b_ff1, w_ff2, b_ff2)
+            self.blocks_keep.append(keep)
+            for name, t in zip(("w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2"), keep):
+                setattr(self.block_arr[i], name, t.data_ptr())
+        self.final_w, self.final_b = f("norm_out.linear.weight"), f("norm_out.linear.bias")
+        self.proj_w, self.proj_b = f("proj_out.weight").to(BF), f("proj_out.bias")
+        self.row_stride = L * 6 * D + 2 * D
+        self.rope_heads = cfg.heads if cfg.pe_attn_head is None else cfg.pe_attn_head
+        self._graphs: Dict[tuple, "_LoopGraph"] = {}
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ once-per-call pieces
+
+    def time_tables(self, t: Tensor) -> Tensor:
+        """t: f32 [E] (or [E, rows]) -> modulation table [E, rows, L*6D + 2D] f32 (K2 + the AdaLN linears)."""
+        cfg, dv = self.cfg, self.device
+        t2 = t.reshape(t.shape[0], -1)
+        E, rows = t2.shape
+        flat = t2.reshape(-1).contiguous()
+        sin = torch.empty(E * rows, 256, device=dv)
+        ops.sinus_embed(flat, self.sinus_freqs, sin)
+        h = torch.empty(E * rows, cfg.dim, device=dv)
+        ops.gemm_f32(sin, self.tm_w0, self.tm_b0, out=h, act=ops.ACT_SILU)
+        temb = torch.empty(E * rows, cfg.dim, device=dv)
+        ops.gemm_f32(h, self.tm_w2, self.tm_b2, out=temb)
+        mod = torch.empty(E * rows, self.row_stride, device=dv)
+        D = cfg.dim
+        for l, (w, b) in enumerate(self.adaln):
+            ops.gemm_f32(temb, w, b, out=mod[:, l * 6 * D:(l + 1) * 6 * D], a_act=ops.ACT_SILU)
+        ops.gemm_f32(temb, self.final_w, self.final_b, out=mod[:, self.L * 6 * D:], a_act=ops.ACT_SILU)
+        self._last_temb = temb
+        return mod.view(E, rows, self.row_stride)
+
+    def text_embed(self, text: Optional[Tensor], B: int, N: int, drop_text: bool) -> Tensor:
+        """TextEmbedding.forward (backbones/dit.py:54-87) -> f32 [B, N, text_dim]."""
+        cfg, dv = self.cfg, self.device
+        keep = None
+        if text is None:
+            ids = torch.zeros(B, N, dtype=I32, device=dv)
+        else:
+            ids = (text.to(dv) + 1)[:, :N]
+            ids = torch.nn.functional.pad(ids, (0, N - ids.shape[1]), value=0)
+            if cfg.text_mask_padding:
+                keep = (ids != 0).to(F32).contiguous()  # mask taken BEFORE the drop (dit.py:62-66)
+            if drop_text:
+                ids = torch.zeros_like(ids)
+            ids = ids.to(I32).contiguous()
+        TD = cfg.text_dim
+        h = torch.empty(B, N, TD, device=dv)
+        # reference masks only when there are conv blocks (the masked_fill sits inside `if self.extra_modeling`)
+        ops.text_gather(ids, self.text_table, self.text_pos, keep if self.text_blocks else None, h)
+        if not self.text_blocks:
+            return h
+        c = torch.empty_like(h)
+        n = torch.empty_like(h)
+        p1 = torch.empty(B, N, 2 * TD, device=dv)
+        g = torch.empty_like(p1)
+        gws = torch.empty(B, 2 * TD, device=dv)
+        keep_flat = keep.view(-1) if keep is not None else None
+        for blk in self.text_blocks:
+            ops.dwconv7(h, blk["dw_w"], blk["dw_b"], c)
+            ops.layernorm(c.view(B * N, TD), n.view(B * N, TD), gamma=blk["ln_g"], beta=blk["ln_b"])
+            ops.gemm_f32(n.view(B * N, TD), blk["w1"], blk["b1"], out=p1.view(B * N, 2 * TD), act=ops.ACT_GELU_ERF)
+            ops.grn(p1, g, blk["grn_g"], blk["grn_b"], gws)
+            h_new = torch.empty_like(h)
+            ops.gemm_f32(g.view(B * N, 2 * TD), blk["w2"], blk["b2"], out=h_new.view(B * N, TD),
+                         addend=h.view(B * N, TD), row_scale=keep_flat)
+            h = h_new
+        return h
+
+    def ppg_embed(self, ppg: Optional[Tensor], B: int, N: int, drop_ppg: bool) -> Tensor:
+        """PPGEmbedding.forward (backbones/dit.py:140-153), BatchNorm folded -> f32 [B, N, text_dim]."""
+        cfg, dv, P = self.cfg, self.device, self.ppg
+        pd = cfg.ppg_dim
+        x = torch.zeros(B, N, pd, device=dv)
+        if ppg is not None and not drop_ppg:
+            x[:, : ppg.shape[1]] = ppg.to(dv, F32)[:, :N]
+        h = torch.empty(B * N, pd, device=dv)
+        ops.gemm_f32(x.view(B * N, pd), P["w0"], P["b0"], out=h)
+        col = torch.empty(B, N, 5 * pd, device=dv)
+        for wf, bf in P["convs"]:
+            ops.im2col(h.view(B, N, pd), col, 5, 2)
+            h2 = torch.empty_like(h)
+            ops.gemm_f32(col.view(B * N, 5 * pd), wf, bf, out=h2, act=ops.ACT_RELU)
+            h = h2
+        out = torch.empty(B, N, cfg.text_dim, device=dv)
+        ops.gemm_f32(h, P["w15"], P["b15"], out=out.view(B * N, cfg.text_dim))
+        return out
+
+    def input_const(self, cond: Tensor, text_emb: Tensor, ppg_emb: Optional[Tensor], drop_audio_cond: bool,
+                    out: Tensor) -> None:
+        """The (cond, text, ppg) columns of InputEmbedding.proj + bias (backbones/dit.py:169-175) -> out f32 [B*N, D]."""
+        cfg = self.cfg
+        B, N, mel = cond.shape
+        TD = cfg.text_dim
+        M = B * N
+        w = self.in_w
+        cur = None
+        if ppg_emb is not None:
+            cur = torch.empty(M, cfg.dim, device=self.device)
+            ops.gemm_f32(ppg_emb.view(M, TD), w[:, 2 * mel + TD: 2 * mel + 2 * TD], None, out=cur)
+        last_is_text = drop_audio_cond
+        dst = out if last_is_text else torch.empty(M, cfg.dim, device=self.device)
+        ops.gemm_f32(text_emb.view(M, TD), w[:, 2 * mel: 2 * mel + TD], self.in_b, out=dst, addend=cur)
+        if not drop_audio_cond:
+            ops.gemm_f32(cond.reshape(M, mel), w[:, mel: 2 * mel], None, out=out, addend=dst)
+
+    def rope_table(self, N: int) -> Tensor:
+        cs = torch.empty(N, 32, 2, device=self.device)
+        ops.rope_table(self.inv_freq, cs)
+        return cs
+
+    # ------------------------------------------------------------------ plan / workspace
+
+    def make_plan(self, S: int, B: int, N: int, y: Tensor, in_const: Tensor, mod: Tensor, eval_ptr: Optional[Tensor],
+                  rope_cs: Tensor, seq_len: Optional[Tensor]) -> "_Plan":
+        cfg, dv = self.cfg, self.device
+        D, H, mel = cfg.dim, cfg.heads, cfg.mel_dim
+        n_pad = (N + 63) // 64 * 64
+        M = S * N
+        ws = dict(
+            h0=torch.empty(M, D, device=dv), h0_bf16=torch.empty(M, D, device=dv, dtype=BF),
+            c1=torch.empty(M, D, device=dv, dtype=BF), x=torch.empty(M, D, device=dv),
+            hn=torch.empty(M, D, device=dv, dtype=BF),
+            q=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF), k=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF),
+            vt=torch.zeros(S, H, 64, n_pad, device=dv, dtype=BF),
+            ao=torch.empty(M, self.inner, device=dv, dtype=BF), ff=torch.empty(M, self.FF, device=dv, dtype=BF),
+            pred=torch.empty(M, mel, device=dv))
+        p = _C.DitPlan()
+        p.S, p.B, p.N, p.n_pad, p.D, p.H = S, B, N, n_pad, D, H
+        p.rope_heads, p.FF, p.L, p.mel, p.mod_rows = self.rope_heads, self.FF, self.L, mel, mod.shape[1]
+        p.y = y.data_ptr()
+        p.w_x, p.ldw_x = self.in_w.data_ptr(), self.in_w.stride(0)
+        p.in_const = in_const.data_ptr()
+        p.convpos_w1, p.convpos_b1 = self.cp[0][0].data_ptr(), self.cp[0][1].data_ptr()
+        p.convpos_w2, p.convpos_b2 = self.cp[1][0].data_ptr(), self.cp[1][1].data_ptr()
+        p.rope_cs = rope_cs.data_ptr()
+        p.seq_len = seq_len.data_ptr() if seq_len is not None else None
+        p.mod = mod.data_ptr()
+        p.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
+        p.blocks = self.block_arr
+        p.w_proj, p.b_proj = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+        for k, t in ws.items():
+            setattr(p, k, t.data_ptr())
+        return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len))
+
+    def forward(self, plan: "_Plan") -> Tensor:
+        ops.dit_forward(plan.c)
+        return plan.ws["pred"]
+
+
+class _Plan:
+    def __init__(self, c_plan, ws, keep):
+        self.c, self.ws, self.keep = c_plan, ws, keep
+
+
+class _LoopGraph:
+    """A captured ODE step bound to fixed buffers; guarded by a lock because replay mutates those buffers."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.graph: Optional[ops.Graph] = None
+        self.buf: dict = {}
+
+
+@dataclass
+class SamplerInputs:
+    """Everything the loop needs, already on the device (built by CFM.sample*)."""
+    step_cond: Tensor            # [B, N, mel] f32
+    text: Optional[Tensor]       # [B, nt] int64 (pad -1) or None
+    ppg: Optional[Tensor]        # [B, np, ppg_dim] or None
+    y0: Tensor                   # [B, N, mel] f32
+    t: Tensor                    # [steps+1] f32 time grid (host or device)
+    seq_len: Optional[Tensor]    # [B] int32 durations, or None when B == 1 (reference: mask=None)
+    branches: List[Tuple[bool, bool, bool]]  # (drop_audio_cond, drop_text, drop_ppg) per CFG branch, p0 first
+    mode: int                    # 0 plain, 1 cfg, 2 three-branch
+    w0: float = 0.0
+    w1: float = 0.0
+    method: str = "euler"
+
+
+def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True) -> Tensor:
+    """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint).
+
+    Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
+    """
+    cfg, dv = engine.cfg, engine.device
+    B, N, mel = inp.y0.shape
+    nb = len(inp.branches)
+    S = nb * B
+    t = inp.t.detach().to("cpu", torch.float32)
+    steps = t.shape[0] - 1
+    if inp.method == "euler":
+        eps_per_step = 1
+        t_eval = t[:-1].clone()
+        coef = (t[1:] - t[:-1]).clone()
+    elif inp.method == "midpoint":
+        eps_per_step = 2
+        dt = t[1:] - t[:-1]
+        half = 0.5 * dt
+        t_eval = torch.stack((t[:-1], t[:-1] + half), 1).reshape(-1)
+        coef = torch.stack((half, dt), 1).reshape(-1)
+    else:
+        raise _C.F5EError(f"unsupported ODE method {inp.method!r} (euler, midpoint)")
+    E = steps * eps_per_step
+
+    # once-per-call tensors
+    mod = engine.time_tables(t_eval.to(dv))                       # [E, 1, row_stride]
+    in_const = torch.empty(S * N, cfg.dim, device=dv)
+    cache: Dict[tuple, Tensor] = {}
+    for bi, (da, dt_, dp) in enumerate(inp.branches):
+        tk = ("t", dt_)
+        if tk not in cache:
+            cache[tk] = engine.text_embed(inp.text, B, N, dt_)
+        pe = None
+        if cfg.use_ppg:
+            pk = ("p", dp)
+            if pk not in cache:
+                cache[pk] = engine.ppg_embed(inp.ppg, B, N, dp)
+            pe = cache[pk]
+        engine.input_const(inp.step_cond, cache[tk], pe, da, in_const[bi * B * N:(bi + 1) * B * N])
+    rope_cs = engine.rope_table(N)
+    seq_len = None
+    if inp.seq_len is not None:
+        seq_len = inp.seq_len.to(dv, I32).repeat(nb).contiguous()
+    coef_d = coef.to(dv).contiguous()
+    eval_ptr = torch.zeros(1, dtype=I32, device=dv)
+    n = B * N * mel
+    traj = torch.empty((steps + 1) if want_trajectory else 2, B, N, mel, device=dv)
+    traj[0].copy_(inp.y0)
+    y = inp.y0.detach().clone().contiguous()
+    y_mid = torch.empty_like(y) if eps_per_step == 2 else None
+
+    plan_a = engine.make_plan(S, B, N, y, in_const, mod, eval_ptr, rope_cs, seq_len)
+    plan_b = engine.make_plan(S, B, N, y_mid, in_const, mod, eval_ptr, rope_cs, seq_len) if y_mid is not None else None
+
+    def one_step(traj_row: Optional[Tensor]):
+        engine.forward(plan_a)
+        if eps_per_step == 1:
+            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row)
+            ops.advance_eval(eval_ptr)
+        else:
+            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None)
+            ops.advance_eval(eval_ptr)
+            engine.forward(plan_b)
+            ops.ode_update(plan_b.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row)
+            ops.advance_eval(eval_ptr)
+
+    if use_graph and steps > 1:
+        gr = ops.Graph()
+        gr.begin()
+        try:
+            one_step(None)
+        finally:
+            gr.end()
+        for i in range(steps):
+            gr.launch()
+            if want_trajectory:
+                traj[i + 1].copy_(y)
+    else:
+        for i in range(steps):
+            one_step(traj[i + 1] if want_trajectory else None)
+    if not want_trajectory:
+        traj[1].copy_(y)
+    return traj

@@ -1,0 +1,269 @@
+"""Torch-tensor front for the C ABI: pointer extraction, shape inference and loud validation.  PyTorch here only owns
+device memory and the stream; every computation happens in libf5e_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _C
+from ._C import ACT_GELU_ERF, ACT_GELU_TANH, ACT_MISH, ACT_NONE, ACT_RELU, ACT_SILU, check, lib  # noqa: F401
+
+Tensor = torch.Tensor
+_checked_device = False
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device() -> None:
+    """Raise unless a gfx950 device is current and the library is loadable."""
+    global _checked_device
+    if not _checked_device:
+        if not torch.cuda.is_available():
+            raise _C.F5EError("f5e_tts_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False and there "
+                              "is no CPU fallback")
+        check(lib().f5e_check_device(), "f5e_check_device")
+        _checked_device = True
+
+
+def _p(t: Optional[Tensor], dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _C.F5EError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise _C.F5EError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise _C.F5EError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+BF, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
+
+
+def gemm_bf16_bias(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, act: int = ACT_NONE, tile_hint: int = 0):
+    """out[M,N] = act(a[M,K] @ w[N,K].T + bias); out bf16 or f32 (no activation)."""
+    require_device()
+    M, K = a.shape
+    N = w.shape[0]
+    check(lib().f5e_gemm_bf16_bias(_stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0),
+                                   _p(bias, F32, "bias"), _p(out, None, "out"), out.stride(0), M, N, K, act,
+                                   1 if out.dtype == F32 else 0, tile_hint), "f5e_gemm_bf16_bias")
+    return out
+
+
+def gemm_bf16_gate_residual(a: Tensor, w: Tensor, bias: Optional[Tensor], resid: Tensor, gate: Tensor,
+                            rows_per_seq: int, seq_len: Optional[Tensor] = None, eval_ptr: Optional[Tensor] = None,
+                            eval_stride: int = 0, tile_hint: int = 0):
+    """resid[M,N] += gate[seq % rows] * (a @ w.T + bias), rows past seq_len skipped. gate: [rows, N] f32 view."""
+    require_device()
+    M, K = a.shape
+    N = w.shape[0]
+    check(lib().f5e_gemm_bf16_gate_residual(
+        _stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0), _p(bias, F32, "bias"),
+        _p(resid, F32, "resid"), resid.stride(0), C.c_void_p(gate.data_ptr()), gate.stride(0), gate.shape[0],
+        _p(eval_ptr, I32, "eval_ptr"), eval_stride, rows_per_seq, _p(seq_len, I32, "seq_len"), M, N, K, tile_hint),
+        "f5e_gemm_bf16_gate_residual")
+    return resid
+
+
+def gemm_bf16_qkv_rope(a: Tensor, w: Tensor, bias: Tensor, q: Tensor, k: Tensor, vt: Tensor, heads: int,
+                       rope_heads: int, cos_sin: Tensor, rows_per_seq: int, tile_hint: int = 0):
+    require_device()
+    M, K = a.shape
+    n_pad = q.shape[2]
+    check(lib().f5e_gemm_bf16_qkv_rope(
+        _stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0), _p(bias, F32, "bias"), _p(q, BF, "q"),
+        _p(k, BF, "k"), _p(vt, BF, "vt"), n_pad, heads, rope_heads, _p(cos_sin, F32, "cos_sin"), rows_per_seq, M, K,
+        tile_hint), "f5e_gemm_bf16_qkv_rope")
+
+
+def flash_attn(q: Tensor, k: Tensor, vt: Tensor, out: Tensor, rows_per_seq: int, kv_len: Optional[Tensor] = None,
+               waves: int = 0):
+    require_device()
+    S, H, n_pad, _ = q.shape
+    check(lib().f5e_flash_attn(_stream(), _p(q, BF, "q"), _p(k, BF, "k"), _p(vt, BF, "vt"), _p(out, BF, "out"),
+                               out.stride(0), _p(kv_len, I32, "kv_len"), S, H, rows_per_seq, n_pad, waves),
+          "f5e_flash_attn")
+    return out
+
+
+def layernorm(x: Tensor, out: Tensor, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
+              scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, rows_per_seq: int = 1,
+              eval_ptr: Optional[Tensor] = None, eval_stride: int = 0, eps: float = 1e-6):
+    """x f32 [rows, D]; scale/shift: f32 [mod_rows, D] views (row stride free)."""
+    require_device()
+    rows, D = x.shape
+    mod_rows = scale.shape[0] if scale is not None else 0
+    mod_stride = scale.stride(0) if scale is not None else 0
+    if scale is not None and shift.stride(0) != mod_stride:
+        raise _C.F5EError("scale and shift must share a row stride")
+    sp = C.c_void_p(scale.data_ptr()) if scale is not None else None
+    hp = C.c_void_p(shift.data_ptr()) if shift is not None else None
+    check(lib().f5e_layernorm(_stream(), _p(x, F32, "x"), x.stride(0), _p(out, None, "out"), out.stride(0),
+                              1 if out.dtype == BF else 0, _p(gamma, F32, "gamma"), _p(beta, F32, "beta"), sp, hp,
+                              mod_stride, mod_rows, rows_per_seq, _p(eval_ptr, I32, "eval_ptr"), eval_stride, rows, D,
+                              eps), "f5e_layernorm")
+    return out
+
+
+def grn(x: Tensor, out: Tensor, gamma: Tensor, beta: Tensor, ws: Tensor):
+    require_device()
+    B, T, Cc = x.shape
+    check(lib().f5e_grn(_stream(), _p(x, F32, "x"), _p(out, F32, "out"), _p(ws, F32, "ws"), _p(gamma, F32, "gamma"),
+                        _p(beta, F32, "beta"), B, T, Cc), "f5e_grn")
+    return out
+
+
+def gemm_f32(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out: Optional[Tensor] = None,
+             out_bf16: Optional[Tensor] = None, M: Optional[int] = None, a_act: int = ACT_NONE, act: int = ACT_NONE,
+             ch_scale: Optional[Tensor] = None, addend: Optional[Tensor] = None, row_scale: Optional[Tensor] = None,
+             K: Optional[int] = None):
+    """fp32 MFMA GEMM; ``a`` [a_rows, >=K] and ``w`` [N, >=K] may be column-sliced views (row stride = ld)."""
+    require_device()
+    a_rows = a.shape[0]
+    K = a.shape[1] if K is None else K
+    N = w.shape[0]
+    M = a_rows if M is None else M
+    for t, nm in ((a, "a"), (w, "w")):
+        if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
+            raise _C.F5EError(f"gemm_f32: {nm} must be an f32 GPU tensor with unit column stride")
+    ad = addend
+    check(lib().f5e_gemm_f32(
+        _stream(), C.c_void_p(a.data_ptr()), a.stride(0), a_rows, a_act, C.c_void_p(w.data_ptr()), w.stride(0),
+        _p(bias, F32, "bias"), act, _p(ch_scale, F32, "ch_scale"),
+        C.c_void_p(ad.data_ptr()) if ad is not None else None, ad.stride(0) if ad is not None else 0,
+        ad.shape[0] if ad is not None else 0, _p(row_scale, F32, "row_scale"),
+        C.c_void_p(out.data_ptr()) if out is not None else None, out.stride(0) if out is not None else 0,
+        C.c_void_p(out_bf16.data_ptr()) if out_bf16 is not None else None,
+        out_bf16.stride(0) if out_bf16 is not None else 0, M, N, K), "f5e_gemm_f32")
+    return out if out is not None else out_bf16
+
+
+def convpos(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_bf16: Optional[Tensor] = None,
+            out_f32: Optional[Tensor] = None, resid: Optional[Tensor] = None):
+    require_device()
+    D = x.shape[1]
+    mode = 0 if out_f32 is None else 1
+    check(lib().f5e_convpos(_stream(), _p(x, BF, "x"), x.stride(0), _p(w_packed, BF, "w_packed"), _p(bias, F32, "bias"),
+                            mode, _p(out_bf16, BF, "out_bf16"), out_bf16.stride(0) if out_bf16 is not None else 0,
+                            _p(out_f32, F32, "out_f32"), out_f32.stride(0) if out_f32 is not None else 0,
+                            _p(resid, F32, "resid"), resid.stride(0) if resid is not None else 0, S, N, D),
+          "f5e_convpos")
+
+
+def dwconv7(x: Tensor, w_t: Tensor, bias: Tensor, out: Tensor):
+    require_device()
+    B, T, Cc = x.shape
+    check(lib().f5e_dwconv7(_stream(), _p(x, F32, "x"), _p(w_t, F32, "w_t"), _p(bias, F32, "bias"), _p(out, F32, "out"),
+                            B, T, Cc), "f5e_dwconv7")
+    return out
+
+
+def im2col(x: Tensor, col: Tensor, ksize: int, pad: int):
+    require_device()
+    B, T, Cin = x.shape
+    check(lib().f5e_im2col(_stream(), _p(x, F32, "x"), _p(col, F32, "col"), B, T, Cin, ksize, pad), "f5e_im2col")
+    return col
+
+
+def sinus_embed(t: Tensor, freqs: Tensor, out: Tensor, scale: float = 1000.0):
+    require_device()
+    E, dim = out.shape
+    check(lib().f5e_sinus_embed(_stream(), _p(t, F32, "t"), _p(freqs, F32, "freqs"), _p(out, F32, "out"), E, dim, scale),
+          "f5e_sinus_embed")
+    return out
+
+
+def rope_table(inv_freq: Tensor, out: Tensor):
+    require_device()
+    N, half, _ = out.shape
+    check(lib().f5e_rope_table(_stream(), _p(inv_freq, F32, "inv_freq"), _p(out, F32, "out"), N, half), "f5e_rope_table")
+    return out
+
+
+def text_gather(ids: Tensor, table: Tensor, pos: Optional[Tensor], keep: Optional[Tensor], out: Tensor):
+    require_device()
+    B, N, TD = out.shape
+    check(lib().f5e_text_gather(_stream(), _p(ids, I32, "ids"), _p(table, F32, "table"), _p(pos, F32, "pos"),
+                                _p(keep, F32, "keep"), _p(out, F32, "out"), B, N, TD,
+                                pos.shape[0] if pos is not None else 1), "f5e_text_gather")
+    return out
+
+
+def ode_update(pred: Tensor, branch_stride: int, mode: int, w0: float, w1: float, base: Tensor, dst: Tensor,
+               coef: Tensor, eval_ptr: Optional[Tensor], traj: Optional[Tensor] = None):
+    require_device()
+    check(lib().f5e_ode_update(_stream(), _p(pred, F32, "pred"), branch_stride, mode, w0, w1, _p(base, F32, "base"),
+                               _p(dst, F32, "dst"), C.c_void_p(traj.data_ptr()) if traj is not None else None,
+                               _p(coef, F32, "coef"), _p(eval_ptr, I32, "eval_ptr"), base.numel()), "f5e_ode_update")
+    return dst
+
+
+def advance_eval(eval_ptr: Tensor):
+    require_device()
+    check(lib().f5e_advance_eval(_stream(), _p(eval_ptr, I32, "eval_ptr")), "f5e_advance_eval")
+
+
+def stitch(cond: Tensor, y: Tensor, mask_u8: Tensor, out: Tensor):
+    require_device()
+    Cc = cond.shape[-1]
+    check(lib().f5e_stitch(_stream(), _p(cond, F32, "cond"), _p(y, F32, "y"), _p(mask_u8, U8, "mask"),
+                           _p(out, F32, "out"), cond.numel() // Cc, Cc), "f5e_stitch")
+    return out
+
+
+def cast_bf16(x: Tensor, out: Tensor):
+    require_device()
+    check(lib().f5e_cast_bf16(_stream(), _p(x, F32, "x"), _p(out, BF, "out"), x.numel()), "f5e_cast_bf16")
+    return out
+
+
+def stft_logmel(wav: Tensor, window: Tensor, twiddle: Tensor, fb: Tensor, out: Tensor, n_fft: int, hop: int):
+    require_device()
+    B, nw = wav.shape
+    check(lib().f5e_stft_logmel(_stream(), _p(wav, F32, "wav"), nw, wav.stride(0), _p(window, F32, "window"),
+                                _p(twiddle, F32, "twiddle"), _p(fb, F32, "fb"), _p(out, F32, "out"), B, n_fft, hop,
+                                fb.shape[1]), "f5e_stft_logmel")
+    return out
+
+
+def istft_head(z: Tensor, window: Tensor, twiddle: Tensor, frames_ws: Tensor, out: Tensor, B: int, T: int, n_fft: int,
+               hop: int):
+    require_device()
+    check(lib().f5e_istft_head(_stream(), _p(z, F32, "z"), z.stride(0), _p(window, F32, "window"),
+                               _p(twiddle, F32, "twiddle"), _p(frames_ws, F32, "frames_ws"), _p(out, F32, "out"), B, T,
+                               n_fft, hop), "f5e_istft_head")
+    return out
+
+
+def dit_forward(plan: "_C.DitPlan"):
+    require_device()
+    check(lib().f5e_dit_forward(_stream(), C.byref(plan)), "f5e_dit_forward")
+
+
+class Graph:
+    """hipGraph captured through the C ABI on the current (non-default) torch stream."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+
+    def begin(self):
+        require_device()
+        check(lib().f5e_graph_begin(_stream()), "f5e_graph_begin")
+
+    def end(self):
+        check(lib().f5e_graph_end(_stream(), C.byref(self.handle)), "f5e_graph_end")
+
+    def launch(self):
+        check(lib().f5e_graph_launch(self.handle, _stream()), "f5e_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().f5e_graph_destroy(self.handle)
+        except Exception:
+            pass

@@ -1,0 +1,190 @@
+/* f5e_abi.h -- C ABI of libf5e_hip.so: the MI355X (gfx950) kernels of the F5E-TTS flow-matching inference hot path.
+ *
+ * The reference (kaleo996/F5E-TTS) has no FFI for this path: it is a chain of PyTorch nn.Module calls.  Each entry
+ * point below therefore replaces a *PyTorch op sequence*; the comment on each names the reference lines
+ * (paths relative to src/f5_tts/).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions (lower side)
+ *   - plain pointers and ints only; every pointer is a DEVICE pointer unless the name says "host".
+ *   - the caller owns every buffer (workspace included); the library never allocates, frees or synchronises inside
+ *     an op, so every op is capturable into a hipGraph (f5e_graph_*).
+ *   - hipStream_t is passed as void* (the value of torch.cuda.current_stream().cuda_stream).
+ *   - row-major; "ld*" = leading dimension in ELEMENTS; bf16 = 16-bit brain float, f32 = IEEE binary32.
+ *   - return value: 0 = F5E_OK, negative = error; message via f5e_last_error() (thread local).  No C++ exception
+ *     crosses the ABI.  Re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef F5E_ABI_H_
+#define F5E_ABI_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F5E_ABI_VERSION 1
+
+enum { F5E_OK = 0, F5E_ERR_BAD_SHAPE = -1, F5E_ERR_UNSUPPORTED = -2, F5E_ERR_HIP = -3 };
+
+/* activation selectors */
+enum { F5E_ACT_NONE = 0, F5E_ACT_SILU = 1, F5E_ACT_GELU_ERF = 2, F5E_ACT_GELU_TANH = 3, F5E_ACT_RELU = 4, F5E_ACT_MISH = 5 };
+
+#ifdef F5E_STREAM_T
+typedef F5E_STREAM_T f5e_stream; /* library build: the real hipStream_t (same ABI: one pointer) */
+#else
+typedef void* f5e_stream; /* hipStream_t */
+#endif
+
+int f5e_abi_version(void);
+const char* f5e_last_error(void);
+/* 0 when the current HIP device is gfx950; F5E_ERR_UNSUPPORTED otherwise (host call, no kernel launch). */
+int f5e_check_device(void);
+
+/* ---------------------------------------------------------------- bf16 MFMA GEMMs (hot loop) ----------------- */
+
+/* out[M][N] = act(A[M][K] . W[N][K]^T + bias).  A, W bf16; bias f32[N] or NULL; out bf16 (out_f32 = 0) or f32.
+ * act: F5E_ACT_NONE or F5E_ACT_GELU_TANH.  K % 64 == 0, N % 4 == 0.  tile_hint 0 = auto.
+ * Replaces: FeedForward project_in + GELU(tanh) (model/modules.py:348-349,625), proj_out (backbones/dit.py:470). */
+int f5e_gemm_bf16_bias(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                       int ldo, int M, int N, int K, int act, int out_f32, int tile_hint);
+
+/* resid[m][n] += gate[(m / rows_per_seq) % gate_rows][n] * (A . W^T + bias)[m][n], skipped for rows whose position
+ * (m % rows_per_seq) >= seq_len[m / rows_per_seq] when seq_len != NULL.  gate is read at
+ * gate + (*eval_ptr) * eval_stride when eval_ptr != NULL.
+ * Replaces: attn.to_out + masked_fill + "x + gate_msa * attn" (modules.py:494-501,635) and
+ *           ff.ff[2] + "x + gate_mlp * ff" (modules.py:350,639). */
+int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                int N, int K, int tile_hint);
+
+/* Fused to_q/to_k/to_v (+bias) + rotary embedding on the first rope_heads heads of q and k.  W = [3*heads*64][K]
+ * (rows: q | k | v).  Outputs: q, k [S][heads][n_pad][64] bf16, vt [S][heads][64][n_pad] bf16 (V transposed).
+ * cos_sin: [rows_per_seq][32][2] f32 from f5e_rope_table.  Pad rows/columns of q/k/vt are never written: the
+ * caller zero-fills them once.
+ * Replaces: modules.py:452-461 (projections + head split) and :470-480 (apply_rotary_pos_emb). */
+int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
+                           void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                           int rows_per_seq, int M, int K, int tile_hint);
+
+/* ---------------------------------------------------------------- attention ---------------------------------- */
+
+/* o[S*rows_per_seq][ldo] (bf16, column = head*64 + d) = softmax(q k^T / 8 + keymask) v, keys >= kv_len[s] masked.
+ * waves: 0 = auto, 2 or 4 (64 or 128 query rows per workgroup).
+ * Replaces: F.scaled_dot_product_attention + transpose/reshape (modules.py:482-492). */
+int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, void* o, int ldo, const int* kv_len,
+                   int S, int H, int rows_per_seq, int n_pad, int waves);
+
+/* ---------------------------------------------------------------- normalisation ------------------------------ */
+
+/* y = LN(x; eps)  [* gamma + beta]  [* (1 + scale[r]) + shift[r]],  r = (row / rows_per_seq) % mod_rows.
+ * x f32 [rows][D]; y bf16 or f32.  D % 256 == 0, D <= 2048.  scale/shift advance by (*eval_ptr) * eval_stride.
+ * Replaces: AdaLayerNorm / ff_norm modulation / AdaLayerNorm_Final (modules.py:308-314,329-335,637) and the affine
+ * LayerNorms of ConvNeXtV2Block (modules.py:253,264) and Vocos. */
+int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* gamma,
+                  const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
+                  int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps);
+
+/* GRN over the sequence axis (modules.py:225-234): x, y f32 [B][T][C]; gx_ws f32 [B][C] scratch. */
+int f5e_grn(f5e_stream st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B, int T,
+            int C);
+
+/* ---------------------------------------------------------------- exact-fp32 GEMM (once per call) ------------ */
+
+/* C[m][n] = ((act(sum_k actA(A[m % a_rows][k]) W[n][k] + bias[n])) * ch_scale[n] + addend[m % add_rows][n]) * row_scale[m]
+ * written to out (f32) and/or out_bf16.  K, lda, ldw multiples of 4.  NULL skips a term.
+ * Replaces the fp32 F.linear calls of TimestepEmbedding, AdaLN emb, TextEmbedding, PPGEmbedding, InputEmbedding.proj
+ * (x columns per step; cond/text/ppg columns once per call) and Vocos. */
+int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int a_act, const float* W, int ldw,
+                 const float* bias, int act, const float* ch_scale, const float* addend, int ld_add, int add_rows,
+                 const float* row_scale, float* out, int ldo, void* out_bf16, int ldo_bf16, int M, int N, int K);
+
+/* ---------------------------------------------------------------- convolutions ------------------------------- */
+
+/* One grouped Conv1d(D, D, 31, groups = D/64, padding = 15) + Mish of ConvPositionEmbedding (modules.py:167-190,
+ * called with mask=None at backbones/dit.py:176).  x bf16 [S*N][ldx]; w_packed bf16 [D/64][31][64 oc][64 ic].
+ * mode 0: out_bf16 = mish(conv + bias); mode 1: out_f32 = mish(conv + bias) + resid. */
+int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
+                void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D);
+
+/* Depthwise Conv1d(C, C, 7, padding 3, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [7][C]. */
+int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
+
+/* col[b][t][j*Cin + ic] = x[b][t + j - pad][ic] (0 outside [0, T)). */
+int f5e_im2col(f5e_stream st, const float* x, float* col, int B, int T, int Cin, int ksize, int pad);
+
+/* ---------------------------------------------------------------- sampler elementwise ------------------------ */
+
+/* out[e] = cat(sin(a), cos(a)), a = (scale * t[e]) * freqs[k]   (modules.py:154-161; freqs = host constant [dim/2]) */
+int f5e_sinus_embed(f5e_stream st, const float* t, const float* freqs, float* out, int E, int dim, float scale);
+/* out[n][i] = (cos, sin)(n * inv_freq[i])   (x_transformers RotaryEmbedding.forward_from_seq_len) */
+int f5e_rope_table(f5e_stream st, const float* inv_freq, float* out, int N, int half);
+/* out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]   (backbones/dit.py:68-80) */
+int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const float* pos, const float* keep, float* out,
+                    int B, int N, int TD, int max_pos);
+/* v = p0 | p0 + (p0 - p1) w0 | w0 (p2 - p1) + w1 (p1 - p0) + p0   (mode 0 | 1 | 2; p_k = pred + k * branch_stride);
+ * dst = base + coef[*eval_ptr] * v; traj (optional) gets a copy.   (model/cfm.py:447, :187, :310 + Euler/midpoint) */
+int f5e_ode_update(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+                   const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr, long long n);
+int f5e_advance_eval(f5e_stream st, int* eval_ptr);
+/* out = mask ? cond : y   (cfm.py:476); mask u8 [rows], tensors f32 [rows][C] */
+int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
+               int C);
+int f5e_cast_bf16(f5e_stream st, const float* x, void* y, long long n);
+
+/* ---------------------------------------------------------------- mel / vocoder ------------------------------ */
+
+/* out[B][T][n_mels] = log(clamp(|STFT(wav)| . fb, 1e-5)), T = 1 + nw / hop, reflect-padded, centred (modules.py:75-101).
+ * window f32 [1024]; twiddle f32 [512][2] = (cos, -sin)(2 pi k / 1024); fb f32 [513][n_mels]. */
+int f5e_stft_logmel(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+                    const float* fb, float* out, int B, int n_fft, int hop, int n_mels);
+/* Vocos ISTFTHead tail: z f32 [B*T][ldz] (513 log-magnitudes | 513 phases) -> out f32 [B][hop * (T - 1)];
+ * frames_ws f32 [B*T][1024] scratch. */
+int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, const float* twiddle, float* frames_ws,
+                   float* out, int B, int T, int n_fft, int hop);
+
+/* ---------------------------------------------------------------- fused DiT evaluation ----------------------- */
+
+typedef struct f5e_dit_block_weights {
+  const void* w_qkv;  const float* b_qkv;  /* bf16 [3*H*64][D], f32 [3*H*64] */
+  const void* w_out;  const float* b_out;  /* bf16 [D][H*64] */
+  const void* w_ff1;  const float* b_ff1;  /* bf16 [FF][D] */
+  const void* w_ff2;  const float* b_ff2;  /* bf16 [D][FF] */
+} f5e_dit_block_weights;
+
+typedef struct f5e_dit_plan {
+  int S, B, N, n_pad, D, H, rope_heads, FF, L, mel;
+  int mod_rows;               /* rows of the modulation table per evaluation (1, or B for per-item times) */
+  /* inputs */
+  const float* y;             /* [B*N][mel] f32: network input (ODE state) */
+  const float* w_x; int ldw_x;/* input_embed.proj.weight[:, :mel] f32 */
+  const float* in_const;      /* [S*N][D] f32: cond/text/ppg part of the input projection + bias, per branch */
+  const void* convpos_w1; const float* convpos_b1;
+  const void* convpos_w2; const float* convpos_b2;
+  const float* rope_cs;       /* [N][32][2] */
+  const int* seq_len;         /* [S] valid frames per sequence, or NULL (= N, the reference's mask=None case) */
+  const float* mod;           /* [E][mod_rows][L*6*D + 2*D] f32 */
+  const int* eval_ptr;        /* device int: current evaluation index into mod */
+  const f5e_dit_block_weights* blocks; /* HOST array [L] */
+  const void* w_proj; const float* b_proj; /* bf16 [mel][D], f32 [mel] */
+  /* workspace (caller-owned, sizes in elements) */
+  float* h0; void* h0_bf16; void* c1;   /* [S*N][D] f32 / bf16 / bf16 */
+  float* x;                              /* [S*N][D] f32 residual stream */
+  void* hn;                              /* [S*N][D] bf16 */
+  void* q; void* k; void* vt;            /* [S][H][n_pad][64] x2, [S][H][64][n_pad] bf16, zero-filled once */
+  void* ao;                              /* [S*N][H*64] bf16 */
+  void* ff;                              /* [S*N][FF] bf16 */
+  float* pred;                           /* [S*N][mel] f32 */
+} f5e_dit_plan;
+
+/* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
+int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
+
+/* ---------------------------------------------------------------- hipGraph capture --------------------------- */
+int f5e_graph_begin(f5e_stream st);
+int f5e_graph_end(f5e_stream st, void** graph_exec_out);
+int f5e_graph_launch(void* graph_exec, f5e_stream st);
+int f5e_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F5E_ABI_H_ */

@@ -1,0 +1,321 @@
+"""Per-kernel parity: every C-ABI op (through f5e_tts_amd.ops -> libf5e_hip.so) against a plain fp32 PyTorch/oracle
+restatement of the same op on the same seeded inputs.  Tolerances are written next to each comparison:
+bf16-output ops are compared at bf16 resolution (2^-8 relative), fp32 ops at 1e-4..1e-5."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import f5e_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import f5e_tts_amd.ops as ops_mod
+    ops_mod.require_device()
+    return ops_mod
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    bad = err > lim
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} " \
+                          f"(ref max {float(b.abs().max()):.3e})"
+
+
+@pytest.mark.parametrize("M,N,K,hint", [(938, 2048, 1024, 0), (938, 1024, 2048, 1), (130, 192, 128, 2), (77, 100, 64, 3),
+                                        (1, 64, 64, 0), (256, 256, 256, 1)])
+def test_gemm_bf16_bias(ops, M, N, K, hint):
+    a = torch.randn(M, K, generator=g(1)).to(BF)
+    w = (torch.randn(N, K, generator=g(2)) / math.sqrt(K)).to(BF)
+    b = torch.randn(N, generator=g(3))
+    ref = a.float() @ w.float().T + b
+    out32 = torch.empty(M, N, device="cuda")
+    ops.gemm_bf16_bias(dev(a), dev(w), dev(b), out32, tile_hint=hint)
+    close(out32, ref, 1e-4, 1e-4, "f32 out")          # fp32 accumulate, only summation order differs
+    out16 = torch.empty(M, N, device="cuda", dtype=BF)
+    ops.gemm_bf16_bias(dev(a), dev(w), dev(b), out16, tile_hint=hint)
+    close(out16, ref, 2 ** -7, 1e-3, "bf16 out")      # one bf16 rounding of the result
+    ops.gemm_bf16_bias(dev(a), dev(w), dev(b), out16, act=ops.ACT_GELU_TANH, tile_hint=hint)
+    close(out16, F.gelu(ref, approximate="tanh"), 2 ** -7, 2e-3, "gelu")
+
+
+def test_gemm_bf16_identity_asymmetric(ops):
+    """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
+    n = 128
+    a = torch.eye(n).to(BF)
+    w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)  # exactly representable, asymmetric
+    out = torch.empty(n, n, device="cuda")
+    for hint in (1, 2, 3):
+        ops.gemm_bf16_bias(dev(a), dev(w), None, out, tile_hint=hint)
+        assert torch.equal(out.cpu(), w.float().T), f"tile {hint}"
+
+
+@pytest.mark.parametrize("M,N,K,rps", [(938, 1024, 1024, 469), (200, 256, 512, 50)])
+def test_gemm_bf16_gate_residual(ops, M, N, K, rps):
+    S = M // rps
+    a = torch.randn(M, K, generator=g(4)).to(BF)
+    w = (torch.randn(N, K, generator=g(5)) / math.sqrt(K)).to(BF)
+    b = torch.randn(N, generator=g(6))
+    x = torch.randn(M, N, generator=g(7))
+    table = torch.randn(3, 2, 5 * N, generator=g(8))            # [eval][rows][stuff]
+    gate_view = table[0, :, N:2 * N]
+    lens = torch.tensor([rps - 3 * (i + 1) for i in range(S)], dtype=torch.int32)
+    lin = a.float() @ w.float().T + b
+    e = 2
+    gsel = table[e, :, N:2 * N]
+    ref = x.clone()
+    for m in range(M):
+        s, pos = divmod(m, rps)
+        if pos < lens[s]:
+            ref[m] += gsel[s % 2] * lin[m]
+    xd = dev(x)
+    td = dev(table)
+    ev = torch.tensor([e], dtype=torch.int32, device="cuda")
+    ops.gemm_bf16_gate_residual(dev(a), dev(w), dev(b), xd, td[0, :, N:2 * N], rps, seq_len=dev(lens), eval_ptr=ev,
+                                eval_stride=table.stride(0))
+    close(xd, ref, 1e-4, 2e-4, "gate residual")
+    assert gate_view.shape == (2, N)
+
+
+@pytest.mark.parametrize("S,N,H,rope_heads,K", [(2, 469, 16, 16, 1024), (3, 70, 2, 1, 128)])
+def test_qkv_rope(ops, S, N, H, rope_heads, K):
+    inner = H * 64
+    n_pad = (N + 63) // 64 * 64
+    a = torch.randn(S * N, K, generator=g(9)).to(BF)
+    w = (torch.randn(3 * inner, K, generator=g(10)) / math.sqrt(K)).to(BF)
+    b = torch.randn(3 * inner, generator=g(11))
+    lin = (a.float() @ w.float().T + b).view(S, N, 3, H, 64).permute(2, 0, 3, 1, 4)  # [3,S,H,N,64]
+    freqs = O.rope_freqs(N, 64)
+    q_ref, k_ref, v_ref = lin[0].clone(), lin[1].clone(), lin[2]
+    q_ref[:, :rope_heads] = O.apply_rope(q_ref[:, :rope_heads], freqs)
+    k_ref[:, :rope_heads] = O.apply_rope(k_ref[:, :rope_heads], freqs)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    cs = torch.empty(N, 32, 2, device="cuda")
+    ops.rope_table(dev(inv), cs)
+    ang = torch.outer(torch.arange(N).float(), inv)
+    close(cs[..., 0], ang.cos(), 0, 2e-6, "cos table")
+    close(cs[..., 1], ang.sin(), 0, 2e-6, "sin table")
+    q = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
+    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, rope_heads, cs, N)
+    close(q[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
+    close(k[:, :, :N], k_ref, 2 ** -7, 4e-3, "k")
+    close(vt[:, :, :, :N].transpose(2, 3), v_ref, 2 ** -7, 4e-3, "v")
+    assert float(q[:, :, N:].abs().max()) == 0 and float(vt[:, :, :, N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("S,H,N,waves,masked", [(2, 16, 469, 0, False), (2, 4, 469, 4, True), (3, 2, 64, 2, True),
+                                                (1, 2, 130, 4, False), (2, 2, 33, 2, True)])
+def test_flash_attn(ops, S, H, N, waves, masked):
+    n_pad = (N + 63) // 64 * 64
+    q = torch.randn(S, H, N, 64, generator=g(12)).to(BF)
+    k = torch.randn(S, H, N, 64, generator=g(13)).to(BF)
+    v = torch.randn(S, H, N, 64, generator=g(14)).to(BF)
+    lens = torch.tensor([N - 5 * i for i in range(S)], dtype=torch.int32) if masked else None
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    if masked:
+        km = torch.arange(N)[None, :] < lens[:, None]
+        s = s.masked_fill(~km[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(S * N, H * 64)
+    qd = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
+    kd = torch.zeros_like(qd)
+    vtd = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
+    qd[:, :, :N] = q.cuda()
+    kd[:, :, :N] = k.cuda()
+    vtd[:, :, :, :N] = v.transpose(2, 3).cuda()
+    out = torch.empty(S * N, H * 64, device="cuda", dtype=BF)
+    ops.flash_attn(qd, kd, vtd, out, N, kv_len=dev(lens) if masked else None, waves=waves)
+    # P is rounded to bf16 before P.V and the output to bf16: 2^-7 relative + small absolute
+    close(out, ref, 2 ** -6, 6e-3, "attention")
+
+
+def test_flash_attn_spike_forces_rescale(ops):
+    """A late key tile with a much larger score forces the online-softmax rescale branch (cdna guide rule 26)."""
+    S, H, N = 1, 1, 256
+    q = torch.randn(S, H, N, 64, generator=g(15)).to(BF)
+    k = torch.randn(S, H, N, 64, generator=g(16)).to(BF)
+    v = torch.randn(S, H, N, 64, generator=g(17)).to(BF)
+    k[0, 0, 200] = (q[0, 0, 17].float() * 4).to(BF)  # score ~ 4*|q|^2/8 >> others, lands in tile 3
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(S * N, H * 64)
+    out = torch.empty(S * N, 64, device="cuda", dtype=BF)
+    ops.flash_attn(dev(q), dev(k), dev(v.transpose(2, 3)), out, N, waves=2)
+    close(out, ref, 2 ** -6, 6e-3, "attention spike")
+
+
+@pytest.mark.parametrize("D", [256, 512, 768, 1024])
+def test_layernorm_variants(ops, D):
+    rows, rps = 150, 50
+    x = torch.randn(rows, D, generator=g(18)) * 3 + 1
+    tab = torch.randn(2, 2, 6 * D, generator=g(19)) * 0.5
+    e = 1
+    sc, sh = tab[e, :, D:2 * D], tab[e, :, 0:D]
+    ln = F.layer_norm(x, (D,), eps=1e-6)
+    seq = torch.arange(rows) // rps % 2
+    ref = ln * (1 + sc[seq]) + sh[seq]
+    td = dev(tab)
+    ev = torch.tensor([e], dtype=torch.int32, device="cuda")
+    out = torch.empty(rows, D, device="cuda", dtype=BF)
+    ops.layernorm(dev(x), out, scale=td[0, :, D:2 * D], shift=td[0, :, 0:D], rows_per_seq=rps, eval_ptr=ev,
+                  eval_stride=tab.stride(0))
+    close(out, ref, 2 ** -7, 2e-3, "ln modulate bf16")
+    gam, bet = torch.randn(D, generator=g(20)), torch.randn(D, generator=g(21))
+    out32 = torch.empty(rows, D, device="cuda")
+    ops.layernorm(dev(x), out32, gamma=dev(gam), beta=dev(bet))
+    close(out32, F.layer_norm(x, (D,), gam, bet, eps=1e-6), 1e-5, 1e-5, "ln affine f32")
+
+
+def test_grn(ops):
+    B, T, C = 2, 77, 192
+    x = torch.randn(B, T, C, generator=g(22))
+    gam, bet = torch.randn(1, 1, C, generator=g(23)), torch.randn(1, 1, C, generator=g(24))
+    out = torch.empty(B, T, C, device="cuda")
+    ops.grn(dev(x), out, dev(gam.view(-1)), dev(bet.view(-1)), torch.empty(B, C, device="cuda"))
+    close(out, O.grn(x, gam, bet), 1e-5, 1e-5, "grn")
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 1024, 100), (469, 512, 1024), (33, 1026, 512), (5, 64, 4)])
+def test_gemm_f32(ops, M, N, K):
+    a = torch.randn(M, K + 12, generator=g(25))[:, :K]          # strided views on purpose (lda != K)
+    w = torch.randn(N, K + 8, generator=g(26))[:, :K] / math.sqrt(K)
+    b = torch.randn(N, generator=g(27))
+    ref = a @ w.T + b
+    out = torch.empty(M, N, device="cuda")
+    ad = torch.empty(M, K + 12, device="cuda").copy_(torch.cat([a, torch.zeros(M, 12)], 1))[:, :K]
+    wd = torch.empty(N, K + 8, device="cuda").copy_(torch.cat([w, torch.zeros(N, 8)], 1))[:, :K]
+    ops.gemm_f32(ad, wd, dev(b), out=out)
+    close(out, ref, 1e-5, 2e-5, "plain")
+    # full epilogue: silu on A, gelu(erf), channel scale, addend with row wrap, row scale, bf16 copy, A row wrap
+    cs, rs = torch.randn(N, generator=g(28)), (torch.rand(2 * M, generator=g(29)) > 0.3).float()
+    add = torch.randn(M, N, generator=g(30))
+    ref2 = ((F.gelu(F.silu(a) @ w.T + b) * cs)[torch.arange(2 * M) % M] + add[torch.arange(2 * M) % M]) * rs[:, None]
+    out2 = torch.empty(2 * M, N, device="cuda")
+    out2b = torch.empty(2 * M, N, device="cuda", dtype=BF)
+    ops.gemm_f32(ad, wd, dev(b), out=out2, out_bf16=out2b, M=2 * M, a_act=ops.ACT_SILU, act=ops.ACT_GELU_ERF,
+                 ch_scale=dev(cs), addend=dev(add), row_scale=dev(rs))
+    close(out2, ref2, 1e-5, 3e-5, "full epilogue")
+    close(out2b, ref2, 2 ** -7, 1e-3, "bf16 copy")
+    for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_MISH, F.mish), (ops.ACT_GELU_TANH, lambda t: F.gelu(t, approximate="tanh"))):
+        ops.gemm_f32(ad, wd, dev(b), out=out, act=act)
+        close(out, fn(ref), 1e-5, 3e-5, f"act {act}")
+
+
+@pytest.mark.parametrize("S,N,D", [(2, 469, 1024), (3, 70, 128), (1, 5, 64)])
+def test_convpos(ops, S, N, D):
+    G = D // 64
+    x = torch.randn(S, N, D, generator=g(31)).to(BF)
+    w = (torch.randn(D, 64, 31, generator=g(32)) / math.sqrt(64 * 31)).to(BF)
+    b = torch.randn(D, generator=g(33)) * 0.1
+    res = torch.randn(S * N, D, generator=g(34))
+    conv = F.conv1d(x.float().permute(0, 2, 1), w.float(), b, padding=15, groups=G).permute(0, 2, 1).reshape(S * N, D)
+    wp = w.view(G, 64, 64, 31).permute(0, 3, 1, 2).contiguous()  # [G][tap][oc][ic]
+    o16 = torch.empty(S * N, D, device="cuda", dtype=BF)
+    ops.convpos(dev(x.view(S * N, D)), dev(wp), dev(b), S, N, out_bf16=o16)
+    close(o16, F.mish(conv), 2 ** -7, 2e-3, "mode 0")
+    o32 = torch.empty(S * N, D, device="cuda")
+    ops.convpos(dev(x.view(S * N, D)), dev(wp), dev(b), S, N, out_f32=o32, resid=dev(res))
+    close(o32, F.mish(conv) + res, 1e-4, 2e-4, "mode 1")
+
+
+def test_dwconv7_im2col(ops):
+    B, T, C = 2, 50, 512
+    x = torch.randn(B, T, C, generator=g(35))
+    w = torch.randn(C, 1, 7, generator=g(36))
+    b = torch.randn(C, generator=g(37))
+    ref = F.conv1d(x.transpose(1, 2), w, b, padding=3, groups=C).transpose(1, 2)
+    out = torch.empty(B, T, C, device="cuda")
+    ops.dwconv7(dev(x), dev(w[:, 0, :].T), dev(b), out)
+    close(out, ref, 1e-5, 1e-5, "dwconv7")
+    Cin, ks = 100, 7
+    xi = torch.randn(B, T, Cin, generator=g(38))
+    wi = torch.randn(64, Cin, ks, generator=g(39)) / 26
+    col = torch.empty(B, T, ks * Cin, device="cuda")
+    ops.im2col(dev(xi), col, ks, 3)
+    o = torch.empty(B * T, 64, device="cuda")
+    ops.gemm_f32(col.view(B * T, ks * Cin), dev(wi.permute(0, 2, 1).reshape(64, ks * Cin)), None, out=o)
+    ref = F.conv1d(xi.transpose(1, 2), wi, None, padding=3).transpose(1, 2).reshape(B * T, 64)
+    close(o, ref, 1e-5, 2e-5, "im2col conv")
+
+
+def test_sampler_elementwise(ops):
+    t = O.sway_time_grid(32, -1.0)
+    half = 128
+    freqs = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+    out = torch.empty(33, 256, device="cuda")
+    ops.sinus_embed(dev(t), dev(freqs), out)
+    close(out, O.sinus_embedding(t), 0, 2e-4, "sinus")  # |arg| up to 1000: 1 ulp of arg is 6e-5
+    B, N, TD = 2, 40, 64
+    ids = torch.randint(0, 30, (B, N), generator=g(40), dtype=torch.int32)
+    table, pos = torch.randn(30, TD, generator=g(41)), O.text_pos_table(TD, 64)
+    keep = (ids != 0).float()
+    te = torch.empty(B, N, TD, device="cuda")
+    ops.text_gather(dev(ids), dev(table), dev(pos), dev(keep), te)
+    close(te, (table[ids.long()] + pos[:N][None]) * keep[..., None], 0, 0, "text gather")
+    n = B * N * 20
+    pred = torch.randn(3, n, generator=g(42))
+    y = torch.randn(n, generator=g(43))
+    coef = torch.tensor([0.1, 0.25, 0.5])
+    ev = torch.tensor([1], dtype=torch.int32, device="cuda")
+    for mode, ref in ((0, y + 0.25 * pred[0]), (1, y + 0.25 * (pred[0] + (pred[0] - pred[1]) * 2.0)),
+                      (2, y + 0.25 * (2.0 * (pred[2] - pred[1]) + 3.0 * (pred[1] - pred[0]) + pred[0]))):
+        dst, traj = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+        ops.ode_update(dev(pred), n, mode, 2.0, 3.0, dev(y), dst, dev(coef), ev, traj)
+        close(dst, ref, 1e-6, 1e-6, f"ode mode {mode}")
+        assert torch.equal(dst, traj)
+    ops.advance_eval(ev)
+    assert int(ev.item()) == 2
+    mask = (torch.rand(B * N, generator=g(44)) > 0.5)
+    c, yy = torch.randn(B * N, 20, generator=g(45)), torch.randn(B * N, 20, generator=g(46))
+    so = torch.empty(B * N, 20, device="cuda")
+    ops.stitch(dev(c), dev(yy), dev(mask.to(torch.uint8)), so)
+    assert torch.equal(so.cpu(), torch.where(mask[:, None], c, yy))
+    xb = torch.empty(n, device="cuda", dtype=BF)
+    ops.cast_bf16(dev(y), xb)
+    assert torch.equal(xb.cpu(), y.to(BF))
+
+
+def fft_tables():
+    k = torch.arange(512, dtype=torch.float64)
+    tw = torch.stack((torch.cos(2 * math.pi * k / 1024), -torch.sin(2 * math.pi * k / 1024)), -1).float()
+    return torch.hann_window(1024), tw
+
+
+@pytest.mark.parametrize("B,frames", [(1, 188), (3, 21)])
+def test_stft_logmel(ops, B, frames):
+    wav = O.synthetic_ref_wave(frames, batch=B)
+    win, tw = fft_tables()
+    out = torch.empty(B, frames, 100, device="cuda")
+    ops.stft_logmel(dev(wav), dev(win), dev(tw), dev(O.mel_filterbank_htk()), out, 1024, 256)
+    ref = O.log_mel_spectrogram(wav).permute(0, 2, 1)
+    close(out, ref, 1e-4, 2e-4, "log-mel")  # log of a sum of |X|: fp32 FFT ordering differences only
+
+
+@pytest.mark.parametrize("B,T", [(1, 281), (2, 9)])
+def test_istft_head(ops, B, T):
+    z = torch.randn(B * T, 1026, generator=g(47))
+    z[:, :513] = z[:, :513] * 1.5 + 1.0   # some log-magnitudes beyond the exp clip at log(100) = 4.6
+    z[0, 5] = 9.0
+    win, tw = fft_tables()
+    mag, ph = z.view(B, T, 1026).transpose(1, 2).chunk(2, dim=1)
+    mag = torch.clip(torch.exp(mag), max=1e2)
+    ref = torch.istft(torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)), 1024, 256, 1024, win, center=True)
+    out = torch.empty(B, 256 * (T - 1), device="cuda")
+    ops.istft_head(dev(z), dev(win), dev(tw), torch.empty(B * T, 1024, device="cuda"), out, B, T, 1024, 256)
+    close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "istft")
