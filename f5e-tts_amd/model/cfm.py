@@ -1,0 +1,186 @@
+"""CFM sampler mirror (reference model/cfm.py:34-482): ``sample`` / ``sample_tts`` / ``sample_vc`` with the reference's
+signatures and return values ``(out, trajectory)``.  Prep (masks, padding, duration clamp, seeded noise, sway grid)
+is index/bookkeeping work done with torch on the host or device; the mel front-end, every network evaluation, the CFG
+combination and the ODE update run in libf5e_hip.so (engine.run_ode).  Training ``forward`` is out of scope.
+
+Documented deviations from the reference-on-GPU (both are identical to the reference-on-CPU):
+  * seeded noise is drawn with the CPU generator in fp32 and uploaded;
+  * the time grid / RoPE angles are always fp32.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _C
+from ..engine import SamplerInputs, run_ode
+from .modules import MelSpec
+from .utils import default, exists, intersperse, lens_to_mask, list_str_to_idx, list_str_to_tensor
+
+F32, I32 = torch.float32, torch.int32
+
+
+class CFM(nn.Module):
+    def __init__(self, transformer: nn.Module, sigma=0.0, odeint_kwargs: dict = dict(method="euler"),
+                 audio_drop_prob=0.3, cond_drop_prob=0.2, num_channels=None, mel_spec_module: nn.Module | None = None,
+                 mel_spec_kwargs: dict = dict(), frac_lengths_mask: tuple[float, float] = (0.7, 1.0),
+                 vocab_char_map: dict[str, int] | None = None, ppg_config=dict(use_ppg=False),
+                 cb_config=dict(use_codebook=False)):
+        super().__init__()
+        self.frac_lengths_mask = frac_lengths_mask
+        self.mel_spec = default(mel_spec_module, MelSpec(**mel_spec_kwargs))
+        self.num_channels = default(num_channels, self.mel_spec.n_mel_channels)
+        self.audio_drop_prob, self.cond_drop_prob = audio_drop_prob, cond_drop_prob
+        self.transformer = transformer
+        self.dim = transformer.dim
+        self.sigma = sigma
+        self.odeint_kwargs = odeint_kwargs
+        self.vocab_char_map = vocab_char_map
+        self.use_ppg = ppg_config["use_ppg"]
+        self.use_cross_mask = ppg_config.get("use_cross_mask", False)
+        if self.use_ppg:
+            self.combined_cond_drop_prob = ppg_config.get("combined_cond_drop_prob")
+        self.use_codebook = cb_config["use_codebook"]
+        self.use_align_loss = cb_config.get("use_align_loss", False)
+        self.use_graph = True  # hipGraph replay of the ODE step; set False to launch eagerly (debugging)
+        self._side_stream = None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------ shared prep (cfm.py:368-428, 449-469)
+
+    def _prepare(self, cond, text, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
+                 duplicate_test, t_inter, edit_mask, use_text):
+        self.eval()
+        dv = self.device
+        if dv.type != "cuda":
+            raise _C.F5EError(f"CFM lives on {dv}: move it to the GPU (there is no CPU path)")
+        if cond.ndim == 2:  # raw wave -> log-mel through the HIP STFT kernel
+            cond = self.mel_spec(cond.to(dv)).permute(0, 2, 1)
+            assert cond.shape[-1] == self.num_channels
+        cond = cond.to(dv, F32)
+        batch, cond_seq_len = cond.shape[:2]
+        if not exists(lens):
+            lens = torch.full((batch,), cond_seq_len, device=dv, dtype=torch.long)
+        lens = lens.to(dv)
+        if use_text and isinstance(text, list):
+            if exists(self.vocab_char_map):
+                if self.use_align_loss or self.use_cross_mask:
+                    text = intersperse(text)
+                text = list_str_to_idx(text, self.vocab_char_map).to(dv)
+            else:
+                text = list_str_to_tensor(text).to(dv)
+            assert text.shape[0] == batch
+        if not use_text:
+            text = None
+        elif exists(text):
+            text = text.to(dv)
+        cond_mask = lens_to_mask(lens)
+        if edit_mask is not None:
+            cond_mask = cond_mask & edit_mask.to(dv)
+        if isinstance(duration, int):
+            duration = torch.full((batch,), duration, device=dv, dtype=torch.long)
+        duration = duration.to(dv)
+        if text is not None:
+            duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)
+        else:
+            duration = torch.maximum(lens + 1, duration)
+        duration = duration.clamp(max=max_duration)
+        n = int(duration.amax())
+        test_cond = None
+        if duplicate_test:
+            test_cond = F.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
+        cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+        if no_ref_audio:
+            cond = torch.zeros_like(cond)
+        cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False).unsqueeze(-1)
+        step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond)).contiguous()
+        seq_len = duration.to(I32) if batch > 1 else None  # reference: mask = None for single inference (cfm.py:425-428)
+        # seeded noise, one item at a time, CPU generator (cfm.py:452-457)
+        y0 = torch.zeros(batch, n, self.num_channels, dtype=F32)
+        for i, dur in enumerate(duration.tolist()):
+            if exists(seed):
+                torch.manual_seed(seed)
+            y0[i, :dur] = torch.randn(dur, self.num_channels, dtype=F32)
+        y0 = y0.to(dv)
+        t_start = 0
+        if duplicate_test:
+            t_start = t_inter
+            y0 = (1 - t_start) * y0 + t_start * test_cond
+            steps = int(steps * (1 - t_start))
+        t = torch.linspace(t_start, 1, steps + 1, dtype=F32)
+        if sway_sampling_coef is not None:
+            t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+        return dict(cond=cond, cond_mask=cond_mask, step_cond=step_cond, text=text, seq_len=seq_len, y0=y0, t=t)
+
+    def _integrate(self, prep, ppg, branches, mode, w0, w1, vocoder):
+        eng = self.transformer.engine()
+        inp = SamplerInputs(step_cond=prep["step_cond"], text=prep["text"], ppg=ppg, y0=prep["y0"], t=prep["t"],
+                            seq_len=prep["seq_len"], branches=branches, mode=mode, w0=w0, w1=w1,
+                            method=self.odeint_kwargs.get("method", "euler"))
+        if self.use_graph:
+            # graph capture needs a non-default stream; order it after the caller's stream and hand back afterwards
+            cur = torch.cuda.current_stream(eng.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=eng.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                trajectory = run_ode(eng, inp, use_graph=True)
+            cur.wait_stream(side)
+        else:
+            trajectory = run_ode(eng, inp, use_graph=False)
+        self.transformer.clear_cache()
+        out = torch.empty_like(trajectory[-1])
+        from .. import ops
+        ops.stitch(prep["cond"].contiguous(), trajectory[-1], prep["cond_mask"].reshape(-1).to(torch.uint8).contiguous(),
+                   out)
+        if exists(vocoder):
+            out = vocoder(out.permute(0, 2, 1))
+        return out, trajectory
+
+    # ------------------------------------------------------------------ public samplers
+
+    @torch.no_grad()
+    def sample(self, cond, text, ppg=None, duration=None, *, lens=None, steps=32, cfg_strength=1.0,
+               sway_sampling_coef=None, seed: Optional[int] = None, max_duration=4096,
+               vocoder: Optional[Callable] = None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
+               edit_mask=None):
+        """reference model/cfm.py:349-482: pred + (pred - null) * cfg_strength, Euler/midpoint on the sway grid."""
+        prep = self._prepare(cond, text, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
+                             duplicate_test, t_inter, edit_mask, use_text=True)
+        if cfg_strength < 1e-5:
+            return self._integrate(prep, ppg, [(False, False, False)], 0, 0.0, 0.0, vocoder)
+        return self._integrate(prep, ppg, [(False, False, False), (True, True, True)], 1, float(cfg_strength), 0.0,
+                               vocoder)
+
+    @torch.no_grad()
+    def sample_tts(self, cond, text, duration=None, *, lens=None, steps=32, alpha_spk=1.0, alpha_txt=1.0,
+                   sway_sampling_coef=None, seed: Optional[int] = None, max_duration=4096,
+                   vocoder: Optional[Callable] = None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
+                   edit_mask=None):
+        """reference model/cfm.py:94-223: alpha_spk (spk_txt - txt) + alpha_txt (txt - null) + null."""
+        prep = self._prepare(cond, text, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
+                             duplicate_test, t_inter, edit_mask, use_text=True)
+        branches = [(True, True, True), (True, False, True), (False, False, True)]  # null, txt, spk_txt
+        return self._integrate(prep, None, branches, 2, float(alpha_spk), float(alpha_txt), vocoder)
+
+    @torch.no_grad()
+    def sample_vc(self, cond, ppg=None, duration=None, *, lens=None, steps=32, alpha_spk=1.0, alpha_ppg=1.0,
+                  sway_sampling_coef=None, seed: Optional[int] = None, max_duration=4096,
+                  vocoder: Optional[Callable] = None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
+                  edit_mask=None):
+        """reference model/cfm.py:226-346: alpha_spk (spk_ppg - ppg) + alpha_ppg (ppg - null) + null, text=None."""
+        prep = self._prepare(cond, None, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
+                             duplicate_test, t_inter, edit_mask, use_text=False)
+        branches = [(True, True, True), (True, True, False), (False, True, False)]  # null, ppg, spk_ppg
+        return self._integrate(prep, ppg, branches, 2, float(alpha_spk), float(alpha_ppg), vocoder)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("flow-matching training loss (reference model/cfm.py:484-590) is out of scope of "
+                                  "the MI355X inference path (SURVEY section 8)")
