@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- mel-frames/sec of the F5TTS_v1_Base flow-matching hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL is used for barriers + one MAX all-reduce only --
+   utterances are independent)
+
+A "step" is one full pass of the hot path over one batch: log-mel front-end (HIP STFT) -> 32 Euler steps of the
+CFG-batched DiT (hipGraph replay) -> stitch -> Vocos decode on the GPU, for BASELINE config C2:
+F5TTS_v1_Base, bf16 MFMA contractions, batch 1, N_ref = 188 frames (2 s), N = 469 frames (5 s), NFE 32, CFG 2.0,
+sway -1, seeded random-init weights (AdaLN-zero tensors re-randomised), synthetic audio / token ids.
+Inputs are resident in HBM when the timed region starts; outputs stay on the device.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- the dominant kernel (QKV/FF bf16 MFMA GEMM class chosen by total time) timed per launch with HIP
+                  events on the launch stream during an eager, in-situ pass of the same workload;
+  cpu_baseline -- the CPU oracle ("port") on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_REF, N_TOTAL, NFE, CFG, SWAY = 188, 469, 32, 2.0, -1.0
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+
+
+def gemm_flops(op, M, D=1024, FF=2048):
+    return {"QKV": 2.0 * M * D * 3 * D, "OUT": 2.0 * M * D * D, "FF1": 2.0 * M * D * FF, "FF2": 2.0 * M * FF * D}[op]
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU share of this process: affinity mask capped at 16 (the GPU box gives 16 cores per GPU; os.cpu_count()
+    reports the whole host and oversubscribes OpenMP)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    from f5e_tts_amd import ops
+    from f5e_tts_amd._C import OP_FF1, OP_FF2, OP_OUT, OP_QKV
+    from f5e_tts_amd.engine import KernelTimer
+    from f5e_tts_amd.model import CFM, DiT
+    from f5e_tts_amd.vocoder import Vocos
+    from oracle import f5e_oracle as O  # only for seeded synthetic inputs/weights and the cpu_baseline leg
+
+    ops.require_device()
+    cfg = O.DiTConfig()
+    sd = O.init_dit_state(cfg, 1234)
+    dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
+    dit.load_state_dict(sd, strict=True)
+    cfm = CFM(transformer=dit).cuda().eval()
+    vs = O.init_vocos_state()
+    voc = Vocos()
+    voc.load_state_dict(vs, strict=False)
+    voc = voc.cuda().eval()
+    wav = O.synthetic_ref_wave(N_REF).cuda()
+    text = O.synthetic_text_ids(N_TOTAL).cuda()
+
+    def one_pass():
+        mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+        return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
+
+    log(f"model ready on cuda:{local_rank}, world {world}")
+    for i in range(args.warmup):
+        one_pass()
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    frames = world * args.steps * N_TOTAL
+    gen_audio_s = world * args.steps * (N_TOTAL - N_REF) * 256 / 24000.0
+    value = frames / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # in-situ per-launch timing: eager launches of the SAME kernels in the SAME order, one op class at a time
+        M = 2 * N_TOTAL
+        cfm.use_graph = False
+        per_op = {}
+        for name, op in (("QKV", OP_QKV), ("OUT", OP_OUT), ("FF1", OP_FF1), ("FF2", OP_FF2)):
+            tm = KernelTimer(op, capacity=NFE * 22 + 8)
+            cfm.kernel_timer = tm
+            one_pass()
+            torch.cuda.synchronize()
+            ms = tm.read_ms()
+            per_op[name] = (sum(ms) / len(ms), len(ms))
+            log(f"roofline pass {name}: {len(ms)} launches, avg {per_op[name][0] * 1e3:.1f} us")
+        cfm.kernel_timer = None
+        cfm.use_graph = True
+        dom = max(per_op, key=lambda k: per_op[k][0] * per_op[k][1])
+        avg_ms = per_op[dom][0]
+        ach = gemm_flops(dom, M) / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": {"QKV": "gemm_bf16_kernel<*,*,EPI_QKV_ROPE>", "OUT": "gemm_bf16_kernel<*,*,EPI_GATE_RES>",
+                               "FF1": "gemm_bf16_kernel<*,*,EPI_BF16_GELU>", "FF2": "gemm_bf16_kernel<*,*,EPI_GATE_RES>"}[dom],
+                    "op": dom, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": per_op[dom][1],
+                    "flop_per_launch": gemm_flops(dom, M),
+                    "all_gemm_avg_us": {k: round(v[0] * 1e3, 2) for k, v in per_op.items()}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample_steps = 2
+        torch.set_num_threads(host_threads())
+        log(f"cpu baseline on {torch.get_num_threads()} threads")
+        wav_c, text_c = wav.cpu(), text.cpu()
+        with torch.inference_mode():
+            O.cfm_sample(sd, cfg, wav_c, text_c, None, N_TOTAL, steps=1, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+            c0 = time.perf_counter()
+            out_c, _ = O.cfm_sample(sd, cfg, wav_c, text_c, None, N_TOTAL, steps=sample_steps, cfg_strength=CFG,
+                                    sway_sampling_coef=SWAY, seed=0)
+            c_loop = time.perf_counter() - c0
+            c1 = time.perf_counter()
+            O.vocos_decode(vs, out_c[:, N_REF:].permute(0, 2, 1))
+            c_voc = time.perf_counter() - c1
+        log(f"cpu baseline: loop sample {c_loop:.2f} s, vocoder {c_voc:.2f} s")
+        est = c_loop * (NFE / sample_steps) + c_voc  # one-off parts (mel, text embed) are < 1% of c_loop
+        cpu_baseline = {"value": round(N_TOTAL / est, 3), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"oracle fp32 on the same B=1 N={N_TOTAL} workload: {sample_steps} of {NFE} Euler steps "
+                                  f"({2 * sample_steps} DiT forwards, {c_loop:.2f} s) scaled x{NFE // sample_steps} + one "
+                                  f"full Vocos decode ({c_voc:.2f} s)"}
+
+    if rank == 0:
+        line = {
+            "metric": "mel_frames_per_sec", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"C2: F5TTS_v1_Base random-init, batch 1 per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
+                                   f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE step, "
+                                   "HIP log-mel front-end + Vocos decode on GPU",
+                       "frames_per_step": N_TOTAL, "parallelism": f"replica x{world} (utterance sharding, no collective "
+                                                                  "on the data path)"},
+            "rtf": round(elapsed / gen_audio_s, 5),
+            "generated_mel_frames_per_sec": round(world * args.steps * (N_TOTAL - N_REF) / elapsed, 2),
+        }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if cpu_baseline is not None:
+            line["cpu_baseline"] = cpu_baseline
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

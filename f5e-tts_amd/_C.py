@@ -36,6 +36,10 @@ SIGNATURES = {
     "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_dit_forward": [_P, _P],
+    "f5e_timer_create": [_I, C.POINTER(C.c_void_p)],
+    "f5e_timer_destroy": [_P],
+    "f5e_timer_reset": [_P],
+    "f5e_timer_read": [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)],
     "f5e_graph_begin": [_P],
     "f5e_graph_end": [_P, C.POINTER(C.c_void_p)],
     "f5e_graph_launch": [_P, _P],
@@ -56,7 +60,10 @@ class DitPlan(C.Structure):
                              "eval_ptr")]
         + [("blocks", C.POINTER(BlockWeights)), ("w_proj", _P), ("b_proj", _P)]
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
+        + [("timer", _P), ("timer_op", _I)]
     )
+
+OP_NONE, OP_INPROJ, OP_CONVPOS, OP_LN, OP_QKV, OP_ATTN, OP_OUT, OP_FF1, OP_FF2, OP_FINAL = range(10)
 
 
 _lib = None

@@ -77,6 +77,67 @@ int f5e_graph_destroy(void* graph_exec) {
   return F5E_OK;
 }
 
+struct F5eTimer {
+  int capacity, count;
+  hipEvent_t* start;
+  hipEvent_t* stop;
+};
+
+int f5e_timer_create(int capacity, void** timer_out) {
+  F5E_REQUIRE(capacity > 0 && timer_out, "timer_create: bad arguments");
+  F5eTimer* t = new F5eTimer{capacity, 0, new hipEvent_t[capacity], new hipEvent_t[capacity]};
+  for (int i = 0; i < capacity; ++i) {
+    HIP_TRY(hipEventCreate(&t->start[i]), "hipEventCreate");
+    HIP_TRY(hipEventCreate(&t->stop[i]), "hipEventCreate");
+  }
+  *timer_out = t;
+  return F5E_OK;
+}
+
+int f5e_timer_destroy(void* timer) {
+  if (!timer) return F5E_OK;
+  F5eTimer* t = (F5eTimer*)timer;
+  for (int i = 0; i < t->capacity; ++i) {
+    (void)hipEventDestroy(t->start[i]);
+    (void)hipEventDestroy(t->stop[i]);
+  }
+  delete[] t->start;
+  delete[] t->stop;
+  delete t;
+  return F5E_OK;
+}
+
+int f5e_timer_reset(void* timer) {
+  F5E_REQUIRE(timer, "timer_reset: null");
+  ((F5eTimer*)timer)->count = 0;
+  return F5E_OK;
+}
+
+int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host) {
+  F5E_REQUIRE(timer && ms_out_host && count_out_host, "timer_read: null");
+  F5eTimer* t = (F5eTimer*)timer;
+  const int n = t->count < max_out ? t->count : max_out;
+  for (int i = 0; i < n; ++i) {
+    HIP_TRY(hipEventSynchronize(t->stop[i]), "hipEventSynchronize");
+    HIP_TRY(hipEventElapsedTime(&ms_out_host[i], t->start[i], t->stop[i]), "hipEventElapsedTime");
+  }
+  *count_out_host = n;
+  return F5E_OK;
+}
+
+// records a start/stop event pair around `call` when the plan's timer selects this op class (eager launches only)
+#define F5E_TIMED(opclass, call)                                                  \
+  do {                                                                            \
+    F5eTimer* tm_ = (p->timer && p->timer_op == (opclass)) ? (F5eTimer*)p->timer : nullptr; \
+    const bool on_ = tm_ && tm_->count < tm_->capacity;                           \
+    if (on_) HIP_TRY(hipEventRecord(tm_->start[tm_->count], st), "hipEventRecord"); \
+    F5E_TRY(call);                                                                \
+    if (on_) {                                                                    \
+      HIP_TRY(hipEventRecord(tm_->stop[tm_->count], st), "hipEventRecord");       \
+      tm_->count++;                                                               \
+    }                                                                             \
+  } while (0)
+
 int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
   F5E_REQUIRE(p, "dit_forward: null plan");
   F5E_REQUIRE(p->S > 0 && p->B > 0 && p->S % p->B == 0 && p->N > 0 && p->L > 0, "dit_forward: bad S/B/N/L");
@@ -89,33 +150,33 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
   const int eval_stride = p->mod_rows * row_stride;
 
   // K4: input projection, x-part per step + hoisted cond/text/ppg part (backbones/dit.py:173-175)
-  F5E_TRY(f5e_gemm_f32(st, p->y, p->mel, p->B * p->N, F5E_ACT_NONE, p->w_x, p->ldw_x, nullptr, F5E_ACT_NONE, nullptr,
+  F5E_TIMED(F5E_OP_INPROJ, f5e_gemm_f32(st, p->y, p->mel, p->B * p->N, F5E_ACT_NONE, p->w_x, p->ldw_x, nullptr, F5E_ACT_NONE, nullptr,
                        p->in_const, D, M, nullptr, p->h0, D, p->h0_bf16, D, M, D, p->mel));
   // K5: conv position embedding + residual (dit.py:176)
-  F5E_TRY(f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D));
-  F5E_TRY(f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D));
+  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D));
+  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D));
 
   for (int l = 0; l < p->L; ++l) {
     const f5e_dit_block_weights& w = p->blocks[l];
     const float* mb = p->mod + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + D, mb, row_stride, p->mod_rows, p->N,
+    F5E_TIMED(F5E_OP_LN, f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + D, mb, row_stride, p->mod_rows, p->N,
                           p->eval_ptr, eval_stride, M, D, 1e-6f));
-    F5E_TRY(f5e_gemm_bf16_qkv_rope(st, p->hn, D, w.w_qkv, D, w.b_qkv, p->q, p->k, p->vt, p->n_pad, p->H, p->rope_heads,
+    F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope(st, p->hn, D, w.w_qkv, D, w.b_qkv, p->q, p->k, p->vt, p->n_pad, p->H, p->rope_heads,
                                    p->rope_cs, p->N, M, D, 0));
-    F5E_TRY(f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
-    F5E_TRY(f5e_gemm_bf16_gate_residual(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D, row_stride,
+    F5E_TIMED(F5E_OP_ATTN, f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
+    F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D, row_stride,
                                         p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D, inner, 0));
-    F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + 4 * D, mb + 3 * D, row_stride, p->mod_rows,
+    F5E_TIMED(F5E_OP_LN, f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + 4 * D, mb + 3 * D, row_stride, p->mod_rows,
                           p->N, p->eval_ptr, eval_stride, M, D, 1e-6f));
-    F5E_TRY(f5e_gemm_bf16_bias(st, p->hn, D, w.w_ff1, D, w.b_ff1, p->ff, p->FF, M, p->FF, D, F5E_ACT_GELU_TANH, 0, 0));
-    F5E_TRY(f5e_gemm_bf16_gate_residual(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D, row_stride,
+    F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias(st, p->hn, D, w.w_ff1, D, w.b_ff1, p->ff, p->FF, M, p->FF, D, F5E_ACT_GELU_TANH, 0, 0));
+    F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D, row_stride,
                                         p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF, 0));
   }
   // K13: final AdaLN (scale, shift order: modules.py:333) + proj_out
   const float* mf = p->mod + (size_t)p->L * 6 * D;
-  F5E_TRY(f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mf, mf + D, row_stride, p->mod_rows, p->N,
+  F5E_TIMED(F5E_OP_LN, f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mf, mf + D, row_stride, p->mod_rows, p->N,
                         p->eval_ptr, eval_stride, M, D, 1e-6f));
-  F5E_TRY(f5e_gemm_bf16_bias(st, p->hn, D, p->w_proj, D, p->b_proj, p->pred, p->mel, M, p->mel, D, F5E_ACT_NONE, 1, 0));
+  F5E_TIMED(F5E_OP_FINAL, f5e_gemm_bf16_bias(st, p->hn, D, p->w_proj, D, p->b_proj, p->pred, p->mel, M, p->mel, D, F5E_ACT_NONE, 1, 0));
   return F5E_OK;
 }
 

@@ -332,7 +332,34 @@ class SamplerInputs:
     method: str = "euler"
 
 
-def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True) -> Tensor:
+class KernelTimer:
+    """HIP-event pairs recorded by f5e_dit_forward around every launch of one op class (eager launches only)."""
+
+    def __init__(self, op: int, capacity: int = 4096):
+        import ctypes as C
+        self.op, self.capacity = op, capacity
+        self.handle = C.c_void_p()
+        _C.check(_C.lib().f5e_timer_create(capacity, C.byref(self.handle)), "f5e_timer_create")
+
+    def reset(self):
+        _C.check(_C.lib().f5e_timer_reset(self.handle), "f5e_timer_reset")
+
+    def read_ms(self) -> List[float]:
+        import ctypes as C
+        buf = (C.c_float * self.capacity)()
+        cnt = C.c_int(0)
+        _C.check(_C.lib().f5e_timer_read(self.handle, buf, self.capacity, C.byref(cnt)), "f5e_timer_read")
+        return [buf[i] for i in range(cnt.value)]
+
+    def __del__(self):
+        try:
+            _C.lib().f5e_timer_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
+            timer: Optional[KernelTimer] = None) -> Tensor:
     """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint).
 
     Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
@@ -386,6 +413,12 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
 
     plan_a = engine.make_plan(S, B, N, y, in_const, mod, eval_ptr, rope_cs, seq_len)
     plan_b = engine.make_plan(S, B, N, y_mid, in_const, mod, eval_ptr, rope_cs, seq_len) if y_mid is not None else None
+    if timer is not None:
+        if use_graph:
+            raise _C.F5EError("KernelTimer brackets eager launches only (use_graph=False)")
+        for pl in (plan_a, plan_b):
+            if pl is not None:
+                pl.c.timer, pl.c.timer_op = timer.handle, timer.op
 
     def one_step(traj_row: Optional[Tensor]):
         engine.forward(plan_a)

@@ -46,6 +46,7 @@ class CFM(nn.Module):
         self.use_codebook = cb_config["use_codebook"]
         self.use_align_loss = cb_config.get("use_align_loss", False)
         self.use_graph = True  # hipGraph replay of the ODE step; set False to launch eagerly (debugging)
+        self.kernel_timer = None  # engine.KernelTimer: per-launch HIP-event timing of one op class (eager mode only)
         self._side_stream = None
 
     @property
@@ -134,7 +135,7 @@ class CFM(nn.Module):
                 trajectory = run_ode(eng, inp, use_graph=True)
             cur.wait_stream(side)
         else:
-            trajectory = run_ode(eng, inp, use_graph=False)
+            trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer)
         self.transformer.clear_cache()
         out = torch.empty_like(trajectory[-1])
         from .. import ops

@@ -173,7 +173,20 @@ typedef struct f5e_dit_plan {
   void* ao;                              /* [S*N][H*64] bf16 */
   void* ff;                              /* [S*N][FF] bf16 */
   float* pred;                           /* [S*N][mel] f32 */
+  /* optional instrumentation (eager launches only, never inside graph capture) */
+  void* timer;                           /* from f5e_timer_create, or NULL */
+  int timer_op;                          /* F5E_OP_* op class to bracket with HIP events */
 } f5e_dit_plan;
+
+enum { F5E_OP_NONE = 0, F5E_OP_INPROJ = 1, F5E_OP_CONVPOS = 2, F5E_OP_LN = 3, F5E_OP_QKV = 4, F5E_OP_ATTN = 5,
+       F5E_OP_OUT = 6, F5E_OP_FF1 = 7, F5E_OP_FF2 = 8, F5E_OP_FINAL = 9 };
+
+/* HIP-event timer: host-side helpers (these DO allocate / synchronise; they are not ops).  f5e_dit_forward records
+ * one start/stop pair around every launch of plan->timer_op, on the stream the kernels are launched on. */
+int f5e_timer_create(int capacity, void** timer_out);
+int f5e_timer_destroy(void* timer);
+int f5e_timer_reset(void* timer);
+int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
 
 /* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
 int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
