@@ -5,52 +5,46 @@
 // Replaces F.scaled_dot_product_attention at reference model/modules.py:482-492 (key-padding mask only, no dropout).
 // Instead of a dense bool mask the kernel takes per-sequence key counts: keys >= kv_len[s] get -inf.
 //
-// Layouts (written by f5e_gemm_bf16_qkv_rope):
-//   Q, K : [S][H][n_pad][64] bf16   (RoPE already applied)
-//   Vt   : [S][H][64][n_pad] bf16   (V transposed: key-contiguous, so the PV "A" fragments are plain 8-B LDS reads)
-//   O    : [S*rows_per_seq][H*64] bf16 (token-major, ready to be the A operand of the out-projection GEMM)
+// Operand layouts ("fragment-major", written by f5e_gemm_bf16_qkv_rope; index helpers in f5e_common.h):
+//   Q, K : per (s, head) tiles of 32 positions: [tile][ks = d/16][pos % 32][h = (d/8) % 2][d % 8]   (bf16)
+//   V    : per (s, head) tiles of 32 keys:      [tile][s16 = (key%32)/16][dt = d/32][d % 32][h][j]  (bf16)
+//          with, inside a 16-key group, key%16 = 8 (j>>2) + 4 h + (j&3)
+// so that the 16 bytes one lane feeds to v_mfma_f32_32x32x16_bf16 are contiguous and the 64 lanes of a wave read
+// 1 KiB contiguous: every fragment is ONE fully coalesced global_load_dwordx4 per lane, straight into registers.
+// At DiT sizes K/V of a head (<= 512 KiB at N = 4096, 59 KiB at N = 469) live in L2, so there is no LDS staging, no
+// barrier and no bank conflict in the main loop; waves are independent and latency is hidden by occupancy plus a
+// one-tile register prefetch.
 //
-// gfx950 design
-//   * one workgroup = NW waves x 32 query rows; every wave owns 32 queries for the whole key sweep.
-//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane owns ONE query (lane&31) and 32 of the
-//     64 keys of a tile, so max/sum are 31 in-lane ops + one half-wave exchange; O^T = V^T . P^T keeps that
-//     query-per-lane ownership, so the online-softmax rescale is lane-local too.
-//   * P never leaves registers: the S^T accumulator is converted to bf16 and used directly as the MFMA B operand
-//     (cdna guide section 3, "An accumulator tile as the next MFMA's operand"); the permuted k order
-//     (key = 16s + 8(j>>2) + 4h + (j&3)) is matched by the V^T fragment addresses.
-//   * K tile [64 keys][64 d] lives in LDS with the 16-B chunk XOR swizzle (chunk ^ ((row>>1)&7)): conflict-free
-//     ds_read_b128; V^T tile [64 d][64 keys] uses 136-B rows: conflict-free ds_read_b64.  Register-staged,
-//     double-buffered (loads for tile t+1 are issued before tile t's MFMAs, written after them): 1 barrier per tile.
+// Work decomposition: one wave = 32 queries (lane owns query lane&31; the two 32-lane halves own interleaved key /
+// d rows as dictated by the MFMA C layout).  A workgroup = NSPLIT waves that split the key tiles of the SAME 32
+// queries (flash-decoding style) and merge their (m, l, O) through LDS at the end -- this is what fills 256 CUs at
+// batch 1 (N = 469: 15 q-tiles x 32 (s, head) x 4 splits = 1920 waves).
+//   S^T = K . Q^T  (lane-local softmax statistics),  O^T = V^T . P^T with P taken from the S^T accumulator registers
+//   (cdna guide section 3 "An accumulator tile as the next MFMA's operand").
 #include "f5e_common.h"
 
 namespace {
 
 struct AttnArgs {
-  const bf16* q; const bf16* k; const bf16* vt;
+  const bf16* q; const bf16* k; const bf16* v;
   bf16* o; int ldo;
   const int* kv_len;  // [S] or null (= rows_per_seq)
   int S, H, rows_per_seq, n_pad;
   float scale_log2e;  // (1/sqrt(64)) * log2(e)
 };
 
-constexpr int KT = 64;         // keys per tile
-constexpr int VT_ROW = 136;    // bytes per V^T LDS row (64 keys * 2 B + 8 B pad)
-constexpr int K_BYTES = KT * 128;
-constexpr int V_BYTES = 64 * VT_ROW;
-constexpr int STAGE_BYTES = K_BYTES + V_BYTES;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
-  constexpr int NT = NW * 64;
-  constexpr int CH = 512 / NT;  // 16-B chunks per thread per operand tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+template <int NSPLIT>
+__global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
+  // merge buffers: per extra wave, per lane: 32 O values + m + l
+  __shared__ float red[(NSPLIT > 1 ? NSPLIT - 1 : 1) * 64 * 34];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
 
-  const int qtiles = (a.rows_per_seq + NW * 32 - 1) / (NW * 32);
+  const int qtiles = (a.rows_per_seq + 31) / 32;
   int bid = blockIdx.x;
   const int qt = bid % qtiles;
   bid /= qtiles;
@@ -58,108 +52,92 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   const int seq = bid / a.H;
   const size_t sh = (size_t)seq * a.H + head;
   const int kv_len = a.kv_len ? min(a.kv_len[seq], a.rows_per_seq) : a.rows_per_seq;
-  const int ntiles = (kv_len + KT - 1) / KT;
+  const int ntiles = (kv_len + 63) / 64;  // 64-key steps
 
+  const bf16* Qg = a.q + sh * a.n_pad * 64;
   const bf16* Kg = a.k + sh * a.n_pad * 64;
-  const bf16* Vg = a.vt + sh * 64 * a.n_pad;
+  const bf16* Vg = a.v + sh * a.n_pad * 64;
 
-  // ---- Q fragments: B operand of S^T = K.Q^T : lane supplies Q[q][16ks + 8hh .. +8] ----
-  const int q_row = qt * NW * 32 + wave * 32 + ql;
-  const int q_row_c = min(q_row, a.n_pad - 1);
+  // Q fragments (B operand of S^T = K.Q^T): 4 x 16 B
   bf16x8 qf[4];
-  {
-    const bf16* qp = a.q + (sh * a.n_pad + q_row_c) * 64 + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + ((size_t)(qt * 4 + ks) * 32 + ql) * 16 + hh * 8);
 
-  // ---- staging plan ----
-  // K tile: chunk i -> (row = i>>3 key, c = i&7); V^T tile: chunk i -> (row = i>>3 d, c = i&7: keys 8c..8c+7)
-  uint4 kreg[CH], vreg[CH];
-  auto load_tile = [&](int t) {
-    const int key0 = t * KT;
+  // this wave's 64-key steps: wave, wave + NSPLIT, ...
+  bf16x8 kf[2][4], vf[2][2][2];   // [t32][ks], [t32][s16][dt]
+  auto load_tile = [&](int t64) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int i = tid + NT * j;
-      const int row = i >> 3, c = i & 7;
-      kreg[j] = *(const uint4*)(Kg + (size_t)(key0 + row) * 64 + c * 8);
-      vreg[j] = *(const uint4*)(Vg + (size_t)row * a.n_pad + key0 + c * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* Ks = smem + buf * STAGE_BYTES;
-    char* Vs = Ks + K_BYTES;
+    for (int t = 0; t < 2; ++t) {
+      const size_t tile = (size_t)t64 * 2 + t;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int i = tid + NT * j;
-      const int row = i >> 3, c = i & 7;
-      *(uint4*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[j];
-      uint2* vp = (uint2*)(Vs + row * VT_ROW + c * 16);
-      vp[0] = make_uint2(vreg[j].x, vreg[j].y);
-      vp[1] = make_uint2(vreg[j].z, vreg[j].w);
+      for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *(const bf16x8*)(Kg + ((tile * 4 + ks) * 32 + ql) * 16 + hh * 8);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          vf[t][s][dt] = *(const bf16x8*)(Vg + ((((tile * 2 + s) * 2 + dt) * 32 + ql) * 2 + hh) * 8);
     }
   };
 
   f32x16 oacc[2];
-  oacc[0] = f32x16{0.f};
-  oacc[1] = f32x16{0.f};
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
 
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
+  int t64 = wave;
+  if (t64 < ntiles) load_tile(t64);
+  while (t64 < ntiles) {
+    // current tile's fragments move to compute registers; the next tile's loads are issued before the MFMAs
+    bf16x8 ck[2][4], cv[2][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ck[t][ks] = kf[t][ks];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) cv[t][s][dt] = vf[t][s][dt];
+    }
+    const int cur = t64;
+    t64 += NSPLIT;
+    if (t64 < ntiles) load_tile(t64);
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);
-    const char* Ks = smem + buf * STAGE_BYTES;
-    const char* Vs = Ks + K_BYTES;
-
-    // ---- S^T tiles: st[kt2][reg] = score(key = 32 kt2 + (reg&3) + 8(reg>>2) + 4hh, query = ql) ----
+    // ---- S^T: st[t][reg] = score(key = 64 cur + 32 t + (reg&3) + 8 (reg>>2) + 4 hh, query = ql) ----
     f32x16 st[2];
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) {
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt2][r] = 0.f;
-      const int row = kt2 * 32 + ql;
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks * 2 + hh;
-        const bf16x8 kf = *(const bf16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kt2], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck[t][ks], qf[ks], st[t], 0, 0, 0);
     }
 
     // ---- online softmax (log2 domain) ----
-    const int key_base = t * KT + 4 * hh;
-    const bool partial = (t * KT + KT > kv_len);
+    const int key_base = cur * 64 + 4 * hh;
+    const bool partial = (cur * 64 + 64 > kv_len);
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = st[kt2][r] * a.scale_log2e;
+        float sc = st[t][r] * a.scale_log2e;
         if (partial) {
-          const int key = key_base + kt2 * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= kv_len) s = -INFINITY;
+          const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= kv_len) sc = -INFINITY;
         }
-        st[kt2][r] = s;
-        mx = fmaxf(mx, s);
+        st[t][r] = sc;
+        mx = fmaxf(mx, sc);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+    const float m_new = fmaxf(m_run, mx);     // finite: every processed tile holds at least one valid key
+    const float alpha = fast_exp2(m_run - m_new);  // first tile: exp2(-inf) = 0
     float rs = 0.f;
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[kt2][r] - m_new);
-        st[kt2][r] = p;
+        const float p = fast_exp2(st[t][r] - m_new);
+        st[t][r] = p;
         rs += p;
       }
     rs += __shfl_xor(rs, 32, 64);
@@ -168,31 +146,51 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
 
-    // ---- O^T += V^T . P^T ; k-step (kt2, s): key(j) = 32kt2 + 16s + 8(j>>2) + 4hh + (j&3) ----
+    // ---- O^T += V^T . P^T ; k-step (t, s): accumulator regs 8s..8s+7 of st[t] are exactly the B fragment ----
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kt2][8 * s + j];
-        const int koff = (kt2 * 32 + s * 16 + 4 * hh) * 2;  // bytes
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[t][8 * s + j];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const char* vrow = Vs + (dt * 32 + ql) * VT_ROW + koff;
-          const uint2 lo = *(const uint2*)(vrow);
-          const uint2 hi = *(const uint2*)(vrow + 16);
-          union { uint4 u; bf16x8 v; } vf;
-          vf.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf, oacc[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv[t][s][dt], pf, oacc[dt], 0, 0, 0);
       }
-
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
-    __syncthreads();
   }
 
-  // ---- normalise + store: oacc[dt][reg] = O[q = ql][d = 32dt + (reg&3) + 8(reg>>2) + 4hh] ----
+  // ---- merge the NSPLIT partial results (same queries, disjoint keys) ----
+  if (NSPLIT > 1) {
+    if (wave > 0) {
+      float* dst = red + ((wave - 1) * 64 + lane) * 34;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dst[r] = oacc[0][r]; dst[16 + r] = oacc[1][r]; }
+      dst[32] = m_run;
+      dst[33] = l_run;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < NSPLIT; ++w) {
+      const float* src = red + ((w - 1) * 64 + lane) * 34;
+      const float m_o = src[32], l_o = src[33];
+      const float m_new = fmaxf(m_run, m_o);
+      // a wave that saw no tile has m = -inf, l = 0, O = 0: its factor is exp2(-inf) = 0 (m_new is finite because
+      // wave 0 always owns tile 0 when kv_len > 0)
+      const float fa = fast_exp2(m_run - m_new), fb = fast_exp2(m_o - m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        oacc[0][r] = oacc[0][r] * fa + src[r] * fb;
+        oacc[1][r] = oacc[1][r] * fa + src[16 + r] * fb;
+      }
+      l_run = l_run * fa + l_o * fb;
+      m_run = m_new;
+    }
+  }
+
+  // ---- normalise + store: oacc[dt][reg] = O[q = ql][d = 32 dt + (reg&3) + 8 (reg>>2) + 4 hh] ----
+  const int q_row = qt * 32 + ql;
   if (q_row < a.rows_per_seq) {
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     bf16* op = a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + 4 * hh;
@@ -208,30 +206,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, const void* vt, void* o, int ldo,
-                              const int* kv_len, int S, int H, int rows_per_seq, int n_pad, int waves) {
-  F5E_REQUIRE(q && k && vt && o, "flash_attn: null pointer");
+extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, const void* v, void* o, int ldo,
+                              const int* kv_len, int S, int H, int rows_per_seq, int n_pad, int splits) {
+  F5E_REQUIRE(q && k && v && o, "flash_attn: null pointer");
   F5E_REQUIRE(S > 0 && H > 0 && rows_per_seq > 0, "flash_attn: empty problem");
   F5E_REQUIRE(n_pad % 64 == 0 && n_pad >= rows_per_seq, "flash_attn: n_pad=%d must be a multiple of 64 and >= %d",
               n_pad, rows_per_seq);
   F5E_REQUIRE(ldo % 4 == 0 && ldo >= H * 64, "flash_attn: bad ldo=%d", ldo);
   AttnArgs a{};
-  a.q = (const bf16*)q; a.k = (const bf16*)k; a.vt = (const bf16*)vt; a.o = (bf16*)o; a.ldo = ldo;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o; a.ldo = ldo;
   a.kv_len = kv_len; a.S = S; a.H = H; a.rows_per_seq = rows_per_seq; a.n_pad = n_pad;
   a.scale_log2e = 0.125f * 1.4426950408889634f;
-  if (waves <= 0) {
-    // fill the 256 CUs: prefer 128-query workgroups only when that still yields >= 256 of them
-    const int g4 = ((rows_per_seq + 127) / 128) * H * S;
-    waves = g4 >= 256 ? 4 : 2;
+  const int grid = ((rows_per_seq + 31) / 32) * H * S;
+  if (splits <= 0) {
+    // aim for >= ~2k waves (2 per SIMD on 256 CUs) without splitting sequences that have few key tiles
+    const int ktiles = (rows_per_seq + 63) / 64;
+    splits = grid >= 2048 ? 1 : (grid >= 1024 ? 2 : 4);
+    while (splits > 1 && splits > ktiles) splits >>= 1;
   }
-  if (waves == 4) {
-    const int grid = ((rows_per_seq + 127) / 128) * H * S;
-    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a);
-  } else if (waves == 2) {
-    const int grid = ((rows_per_seq + 63) / 64) * H * S;
-    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid), dim3(128), 0, st, a);
-  } else {
-    F5E_REQUIRE(false, "flash_attn: waves must be 0 (auto), 2 or 4");
+  switch (splits) {
+    case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid), dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a); break;
+    default: F5E_REQUIRE(false, "flash_attn: splits must be 0 (auto), 1, 2 or 4");
   }
   F5E_LAUNCH_CHECK("flash_attn");
   return F5E_OK;

@@ -54,9 +54,10 @@ __global__ void text_gather_kernel(const int* ids, const float* table, const flo
 //   v = mode 0: p0 | mode 1: p0 + (p0 - p1) * w0 | mode 2: w0 (p2 - p1) + w1 (p1 - p0) + p0
 //   dst = base + coef[eval] * v     (+ optional trajectory row)
 __global__ void ode_update_kernel(const float* pred, size_t branch_stride, int mode, float w0, float w1,
-                                  const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr,
-                                  size_t n) {
-  const float h = coef[eval_ptr ? *eval_ptr : 0];
+                                  const float* base, float* dst, float* traj, const float* coef, int* eval_ptr,
+                                  unsigned* done_ctr, size_t n) {
+  const int e = eval_ptr ? *eval_ptr : 0;
+  const float h = coef[e];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float p0 = pred[i];
     float v = p0;
@@ -69,6 +70,19 @@ __global__ void ode_update_kernel(const float* pred, size_t branch_stride, int m
     const float y = base[i] + h * v;
     dst[i] = y;
     if (traj) traj[i] = y;
+  }
+  // Advance the evaluation counter once every block has read it: the last block to finish bumps it and re-arms the
+  // ticket.  Visibility to the NEXT kernel is given by the kernel boundary; within this kernel only the ticket is
+  // shared, through a device-scope atomic (placement independent).
+  if (done_ctr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned t = atomicAdd(done_ctr, 1u);
+      if (t == gridDim.x - 1) {
+        *eval_ptr = e + 1;
+        *done_ctr = 0u;
+      }
+    }
   }
 }
 
@@ -116,11 +130,13 @@ int f5e_text_gather(hipStream_t st, const int* ids, const float* table, const fl
 }
 
 int f5e_ode_update(hipStream_t st, const float* pred, long long branch_stride, int mode, float w0, float w1,
-                   const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr, long long n) {
+                   const float* base, float* dst, float* traj, const float* coef, int* eval_ptr, unsigned* done_ctr,
+                   long long n) {
   F5E_REQUIRE(pred && base && dst && coef && n > 0, "ode_update: bad arguments");
   F5E_REQUIRE(mode >= 0 && mode <= 2, "ode_update: mode must be 0 (plain), 1 (cfg) or 2 (three-branch)");
+  F5E_REQUIRE(!done_ctr || eval_ptr, "ode_update: done_ctr (auto-advance) needs eval_ptr");
   hipLaunchKernelGGL(ode_update_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, pred, (size_t)branch_stride, mode,
-                     w0, w1, base, dst, traj, coef, eval_ptr, (size_t)n);
+                     w0, w1, base, dst, traj, coef, eval_ptr, done_ctr, (size_t)n);
   F5E_LAUNCH_CHECK("ode_update");
   return F5E_OK;
 }

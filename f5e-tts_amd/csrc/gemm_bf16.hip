@@ -44,7 +44,13 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int BM, int BN, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+  // all but the N youngest vector-memory ops (LDS-DMA stages) done, and this wave's LDS reads retired
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int A_BYTES = BM * BK * 2;
@@ -107,13 +113,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // NSTAGE-deep LDS ring fed by LDS-DMA: NSTAGE-1 K-tiles are in flight while one is consumed.  Counted vmcnt +
+  // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
+  constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
   const int KT = a.K / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < KT) stage(s, s);
+  int buf = 0, nbuf = NSTAGE - 1;
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < KT) stage(buf ^ 1, kt + 1);
+    const int rem = KT - 1 - kt;  // stages issued after tile kt
+    if (NSTAGE >= 4 && rem >= 2) wait_vm_lgkm0<2 * LPT>();
+    else if (NSTAGE >= 3 && rem >= 1) wait_vm_lgkm0<LPT>();
+    else wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
+    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
     const char* As = smem + buf * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
@@ -136,6 +150,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
 
   // ---- epilogue: acc[i][j][r] = C[m = m0+wm0+16j+fr][n = n0+wn0+16i+4fq+r] ----
@@ -188,46 +204,70 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
           v[3] = x3 * cs[2] + x2 * cs[3];
         }
         const size_t sh = (size_t)seq * a.heads + head;
+        // fragment-major layouts consumed by attention.hip (index maps documented there)
+        const int tile = pos >> 5, pr = pos & 31;
         if (which < 2) {
-          bf16* dst = (which == 0 ? a.q : a.k) + (sh * a.n_pad + pos) * 64 + d;
+          bf16* dst = (which == 0 ? a.q : a.k) + sh * a.n_pad * 64 +
+                      ((size_t)(tile * 4 + (d >> 4)) * 32 + pr) * 16 + ((d >> 3) & 1) * 8 + (d & 7);
           *(bf16x4*)dst = f2bf4(v[0], v[1], v[2], v[3]);
         } else {
-          bf16* dst = a.vt + (sh * 64 + d) * a.n_pad + pos;
+          const int s16 = pr >> 4, k16 = pr & 15;
+          const int jj = ((k16 >> 3) << 2) | (k16 & 3), hk = (k16 >> 2) & 1;
+          bf16* dst = a.vt + sh * a.n_pad * 64 +
+                      ((((size_t)(tile * 2 + s16) * 2 + (d >> 5)) * 32 + (d & 31)) * 2 + hk) * 8 + jj;
           dst[0] = (bf16)v[0];
-          dst[(size_t)a.n_pad] = (bf16)v[1];
-          dst[(size_t)2 * a.n_pad] = (bf16)v[2];
-          dst[(size_t)3 * a.n_pad] = (bf16)v[3];
+          dst[16] = (bf16)v[1];
+          dst[32] = (bf16)v[2];
+          dst[48] = (bf16)v[3];
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, int NSTAGE>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = a.tiles_m * a.tiles_n;
-  constexpr int lds = 2 * (BM + BN) * 64 * 2;
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(grid), dim3(256), lds, st, a);
+  constexpr int lds = NSTAGE * (BM + BN) * 64 * 2;
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
+  if (lds > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE>), dim3(grid), dim3(256), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
 
+// tile_hint: 0 = auto; otherwise tile + 10 * stages with tile 1 = 128x128, 2 = 128x64, 3 = 64x64 and stages in
+// {0 (default for the tile), 2, 3, 4}.
 template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
-  // Tile choice: the largest tile that still gives >= ~1 block per CU (256 CUs); tile_hint overrides (tests/tuning).
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int sel = tile_hint;
+  int sel = tile_hint % 10, ns = tile_hint / 10;
   if (sel <= 0) {
-    if (blocks(128, 128) >= 224) sel = 1;
-    else if (blocks(128, 64) >= 224 && EPI != EPI_QKV_ROPE) sel = 2;
+    // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
+    // tools/gemm_tune.py on MI355X has 64x64 / 3 stages fastest for every DiT shape at M = 938
+    if (blocks(128, 128) >= 512) sel = 1;
+    else if (blocks(128, 64) >= 512) sel = 2;
     else sel = 3;
   }
-  switch (sel) {
-    case 1: return launch<128, 128, EPI>(a, st);
-    case 2: return launch<128, 64, EPI>(a, st);
-    default: return launch<64, 64, EPI>(a, st);
+  if (ns == 0) ns = 3;
+  switch (sel * 10 + ns) {
+    case 12: return launch<128, 128, EPI, 2>(a, st);
+    case 13: return launch<128, 128, EPI, 3>(a, st);
+    case 22: return launch<128, 64, EPI, 2>(a, st);
+    case 23: return launch<128, 64, EPI, 3>(a, st);
+    case 24: return launch<128, 64, EPI, 4>(a, st);
+    case 32: return launch<64, 64, EPI, 2>(a, st);
+    case 33: return launch<64, 64, EPI, 3>(a, st);
+    case 34: return launch<64, 64, EPI, 4>(a, st);
+    default:
+      f5e_set_error("gemm_bf16: unknown tile_hint %d", tile_hint);
+      return F5E_ERR_BAD_SHAPE;
   }
 }
 

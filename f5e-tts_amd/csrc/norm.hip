@@ -26,12 +26,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   if (row >= a.rows) return;
   const float* xp = a.x + (size_t)row * a.ldx;
   f32x4 v[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] = *(const f32x4*)(xp + (i * 64 + lane) * 4);
+  // modulation rows are fetched while the x loads are in flight (the kernel is latency-, not bandwidth-limited)
+  const int mrow = a.scale ? (row / a.rows_per_seq) % a.mod_rows : 0;
+  const size_t eoff = (a.scale && a.eval_ptr) ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
+  f32x4 sc[VPL], sh[VPL];
+  if (a.scale) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      sc[i] = *(const f32x4*)(a.scale + eoff + (size_t)mrow * a.mod_stride + c);
+      sh[i] = *(const f32x4*)(a.shift + eoff + (size_t)mrow * a.mod_stride + c);
+    }
+  }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    v[i] = *(const f32x4*)(xp + (i * 64 + lane) * 4);
-    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-  }
+  for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float mean = wave_sum(s) / (float)a.D;
   float ss = 0.f;
 #pragma unroll
@@ -40,18 +51,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)a.D + a.eps);
-  const int mrow = a.scale ? (row / a.rows_per_seq) % a.mod_rows : 0;
-  const size_t eoff = (a.scale && a.eval_ptr) ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (i * 64 + lane) * 4;
     f32x4 y = v[i] * rstd;
     if (a.gamma) y = y * *(const f32x4*)(a.gamma + c) + *(const f32x4*)(a.beta + c);
-    if (a.scale) {
-      const f32x4 sc = *(const f32x4*)(a.scale + eoff + (size_t)mrow * a.mod_stride + c);
-      const f32x4 sh = *(const f32x4*)(a.shift + eoff + (size_t)mrow * a.mod_stride + c);
-      y = y * (1.0f + sc) + sh;
-    }
+    if (a.scale) y = y * (1.0f + sc[i]) + sh[i];
     if (a.y_bf16)
       *(bf16x4*)((bf16*)a.y + (size_t)row * a.ldy + c) = f2bf4(y[0], y[1], y[2], y[3]);
     else

@@ -160,9 +160,24 @@ class DiTEngine:
         self.row_stride = L * 6 * D + 2 * D
         self.rope_heads = cfg.heads if cfg.pe_attn_head is None else cfg.pe_attn_head
         self._graphs: Dict[tuple, "_LoopGraph"] = {}
+        self._tables: Dict[tuple, Tensor] = {}
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ once-per-call pieces
+
+    def time_tables_cached(self, t_host: Tensor) -> Tensor:
+        """Tables depend on the time grid only, so calls that share (steps, sway, solver) share them.  The cache is
+        keyed by the exact grid values and is read-only once built (safe to share between threads)."""
+        key = tuple(t_host.tolist())
+        with self._lock:
+            hit = self._tables.get(key)
+        if hit is None:
+            hit = self.time_tables(t_host.to(self.device))
+            with self._lock:
+                if len(self._tables) >= 8:
+                    self._tables.pop(next(iter(self._tables)))
+                self._tables[key] = hit
+        return hit
 
     def time_tables(self, t: Tensor) -> Tensor:
         """t: f32 [E] (or [E, rows]) -> modulation table [E, rows, L*6D + 2D] f32 (K2 + the AdaLN linears)."""
@@ -385,7 +400,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     E = steps * eps_per_step
 
     # once-per-call tensors
-    mod = engine.time_tables(t_eval.to(dv))                       # [E, 1, row_stride]
+    mod = engine.time_tables_cached(t_eval)                       # [E, 1, row_stride]
     in_const = torch.empty(S * N, cfg.dim, device=dv)
     cache: Dict[tuple, Tensor] = {}
     for bi, (da, dt_, dp) in enumerate(inp.branches):
@@ -405,6 +420,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         seq_len = inp.seq_len.to(dv, I32).repeat(nb).contiguous()
     coef_d = coef.to(dv).contiguous()
     eval_ptr = torch.zeros(1, dtype=I32, device=dv)
+    done = torch.zeros(1, dtype=I32, device=dv)
     n = B * N * mel
     traj = torch.empty((steps + 1) if want_trajectory else 2, B, N, mel, device=dv)
     traj[0].copy_(inp.y0)
@@ -423,14 +439,11 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     def one_step(traj_row: Optional[Tensor]):
         engine.forward(plan_a)
         if eps_per_step == 1:
-            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row)
-            ops.advance_eval(eval_ptr)
+            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
         else:
-            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None)
-            ops.advance_eval(eval_ptr)
+            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None, done)
             engine.forward(plan_b)
-            ops.ode_update(plan_b.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row)
-            ops.advance_eval(eval_ptr)
+            ops.ode_update(plan_b.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
 
     if use_graph and steps > 1:
         gr = ops.Graph()

@@ -81,8 +81,26 @@ def gemm_bf16_qkv_rope(a: Tensor, w: Tensor, bias: Tensor, q: Tensor, k: Tensor,
         tile_hint), "f5e_gemm_bf16_qkv_rope")
 
 
+def qk_frag_index(n_pad: int) -> Tensor:
+    """offset[pos, d] of the fragment-major Q/K layout (attention.hip): [pos/32][d/16][pos%32][(d/8)%2][d%8]."""
+    pos = torch.arange(n_pad)[:, None]
+    d = torch.arange(64)[None, :]
+    return (((pos // 32) * 4 + d // 16) * 32 + pos % 32) * 16 + ((d // 8) % 2) * 8 + d % 8
+
+
+def v_frag_index(n_pad: int) -> Tensor:
+    """offset[key, d] of the fragment-major V layout: [key/32][(key%32)/16][d/32][d%32][h][j], key%16 = 8(j>>2)+4h+(j&3)."""
+    key = torch.arange(n_pad)[:, None]
+    d = torch.arange(64)[None, :]
+    k16 = key % 16
+    j = (k16 // 8) * 4 + k16 % 4
+    h = (k16 // 4) % 2
+    return (((((key // 32) * 2 + (key % 32) // 16) * 2 + d // 32) * 32 + d % 32) * 2 + h) * 8 + j
+
+
 def flash_attn(q: Tensor, k: Tensor, vt: Tensor, out: Tensor, rows_per_seq: int, kv_len: Optional[Tensor] = None,
                waves: int = 0):
+    """q, k, vt: [S, H, n_pad, 64]-sized bf16 buffers in the fragment-major layouts; ``waves`` = KV splits (0 auto)."""
     require_device()
     S, H, n_pad, _ = q.shape
     check(lib().f5e_flash_attn(_stream(), _p(q, BF, "q"), _p(k, BF, "k"), _p(vt, BF, "vt"), _p(out, BF, "out"),
@@ -195,11 +213,14 @@ def text_gather(ids: Tensor, table: Tensor, pos: Optional[Tensor], keep: Optiona
 
 
 def ode_update(pred: Tensor, branch_stride: int, mode: int, w0: float, w1: float, base: Tensor, dst: Tensor,
-               coef: Tensor, eval_ptr: Optional[Tensor], traj: Optional[Tensor] = None):
+               coef: Tensor, eval_ptr: Optional[Tensor], traj: Optional[Tensor] = None,
+               done_ctr: Optional[Tensor] = None):
+    """done_ctr (int32[1], zero): the kernel itself advances *eval_ptr after every block has read it."""
     require_device()
     check(lib().f5e_ode_update(_stream(), _p(pred, F32, "pred"), branch_stride, mode, w0, w1, _p(base, F32, "base"),
                                _p(dst, F32, "dst"), C.c_void_p(traj.data_ptr()) if traj is not None else None,
-                               _p(coef, F32, "coef"), _p(eval_ptr, I32, "eval_ptr"), base.numel()), "f5e_ode_update")
+                               _p(coef, F32, "coef"), _p(eval_ptr, I32, "eval_ptr"), _p(done_ctr, I32, "done_ctr"),
+                               base.numel()), "f5e_ode_update")
     return dst
 
 

@@ -68,10 +68,11 @@ int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W,
 /* ---------------------------------------------------------------- attention ---------------------------------- */
 
 /* o[S*rows_per_seq][ldo] (bf16, column = head*64 + d) = softmax(q k^T / 8 + keymask) v, keys >= kv_len[s] masked.
- * waves: 0 = auto, 2 or 4 (64 or 128 query rows per workgroup).
+ * q, k, v use the fragment-major layouts documented in csrc/attention.hip; splits: KV splits per 32-query tile
+ * (0 = auto, 1, 2 or 4).
  * Replaces: F.scaled_dot_product_attention + transpose/reshape (modules.py:482-492). */
 int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, void* o, int ldo, const int* kv_len,
-                   int S, int H, int rows_per_seq, int n_pad, int waves);
+                   int S, int H, int rows_per_seq, int n_pad, int splits);
 
 /* ---------------------------------------------------------------- normalisation ------------------------------ */
 
@@ -121,9 +122,11 @@ int f5e_rope_table(f5e_stream st, const float* inv_freq, float* out, int N, int 
 int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const float* pos, const float* keep, float* out,
                     int B, int N, int TD, int max_pos);
 /* v = p0 | p0 + (p0 - p1) w0 | w0 (p2 - p1) + w1 (p1 - p0) + p0   (mode 0 | 1 | 2; p_k = pred + k * branch_stride);
- * dst = base + coef[*eval_ptr] * v; traj (optional) gets a copy.   (model/cfm.py:447, :187, :310 + Euler/midpoint) */
+ * dst = base + coef[*eval_ptr] * v; traj (optional) gets a copy.   (model/cfm.py:447, :187, :310 + Euler/midpoint)
+ * done_ctr (optional, one zero-initialised u32): the last workgroup to finish does ++*eval_ptr and re-zeroes it. */
 int f5e_ode_update(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
-                   const float* base, float* dst, float* traj, const float* coef, const int* eval_ptr, long long n);
+                   const float* base, float* dst, float* traj, const float* coef, int* eval_ptr, unsigned* done_ctr,
+                   long long n);
 int f5e_advance_eval(f5e_stream st, int* eval_ptr);
 /* out = mask ? cond : y   (cfm.py:476); mask u8 [rows], tensors f32 [rows][C] */
 int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,

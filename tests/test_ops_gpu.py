@@ -115,14 +115,28 @@ def test_qkv_rope(ops, S, N, H, rope_heads, K):
     k = torch.zeros_like(q)
     vt = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
     ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, rope_heads, cs, N)
-    close(q[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
-    close(k[:, :, :N], k_ref, 2 ** -7, 4e-3, "k")
-    close(vt[:, :, :, :N].transpose(2, 3), v_ref, 2 ** -7, 4e-3, "v")
-    assert float(q[:, :, N:].abs().max()) == 0 and float(vt[:, :, :, N:].abs().max()) == 0
+    qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)   # fragment-major layouts -> [pos, d]
+    unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
+    close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
+    close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k")
+    close(unq(vt, vi)[:, :, :N], v_ref, 2 ** -7, 4e-3, "v")
+    assert float(unq(q, qi)[:, :, N:].abs().max()) == 0 and float(unq(vt, vi)[:, :, N:].abs().max()) == 0
+
+
+def pack_qkv(ops, q, k, v, n_pad):
+    """[S, H, N, 64] tensors -> zero-padded fragment-major device buffers (what the QKV GEMM epilogue writes)."""
+    S, H, N, _ = q.shape
+    qi, vi = ops.qk_frag_index(n_pad)[:N].reshape(-1), ops.v_frag_index(n_pad)[:N].reshape(-1)
+    outs = []
+    for t, idx in ((q, qi), (k, qi), (v, vi)):
+        buf = torch.zeros(S, H, n_pad * 64, dtype=BF)
+        buf[:, :, idx] = t.reshape(S, H, N * 64)
+        outs.append(buf.view(S, H, n_pad, 64).cuda())
+    return outs
 
 
 @pytest.mark.parametrize("S,H,N,waves,masked", [(2, 16, 469, 0, False), (2, 4, 469, 4, True), (3, 2, 64, 2, True),
-                                                (1, 2, 130, 4, False), (2, 2, 33, 2, True)])
+                                                (1, 2, 130, 4, False), (2, 2, 33, 1, True), (1, 16, 1875, 0, False)])
 def test_flash_attn(ops, S, H, N, waves, masked):
     n_pad = (N + 63) // 64 * 64
     q = torch.randn(S, H, N, 64, generator=g(12)).to(BF)
@@ -134,12 +148,7 @@ def test_flash_attn(ops, S, H, N, waves, masked):
         km = torch.arange(N)[None, :] < lens[:, None]
         s = s.masked_fill(~km[:, None, None, :], float("-inf"))
     ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(S * N, H * 64)
-    qd = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
-    kd = torch.zeros_like(qd)
-    vtd = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
-    qd[:, :, :N] = q.cuda()
-    kd[:, :, :N] = k.cuda()
-    vtd[:, :, :, :N] = v.transpose(2, 3).cuda()
+    qd, kd, vtd = pack_qkv(ops, q, k, v, n_pad)
     out = torch.empty(S * N, H * 64, device="cuda", dtype=BF)
     ops.flash_attn(qd, kd, vtd, out, N, kv_len=dev(lens) if masked else None, waves=waves)
     # P is rounded to bf16 before P.V and the output to bf16: 2^-7 relative + small absolute
@@ -156,8 +165,9 @@ def test_flash_attn_spike_forces_rescale(ops):
     s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
     ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(S * N, H * 64)
     out = torch.empty(S * N, 64, device="cuda", dtype=BF)
-    ops.flash_attn(dev(q), dev(k), dev(v.transpose(2, 3)), out, N, waves=2)
-    close(out, ref, 2 ** -6, 6e-3, "attention spike")
+    for splits in (1, 2, 4):
+        ops.flash_attn(*pack_qkv(ops, q, k, v, N), out, N, waves=splits)
+        close(out, ref, 2 ** -6, 6e-3, f"attention spike, {splits} KV splits")
 
 
 @pytest.mark.parametrize("D", [256, 512, 768, 1024])
@@ -279,6 +289,11 @@ def test_sampler_elementwise(ops):
         ops.ode_update(dev(pred), n, mode, 2.0, 3.0, dev(y), dst, dev(coef), ev, traj)
         close(dst, ref, 1e-6, 1e-6, f"ode mode {mode}")
         assert torch.equal(dst, traj)
+    done = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for expect in (2, 3):   # auto-advance: the kernel bumps the evaluation counter itself and re-arms the ticket
+        ops.ode_update(dev(pred), n, 0, 0.0, 0.0, dev(y), dst, torch.ones(8, device="cuda"), ev, None, done)
+        assert int(ev.item()) == expect and int(done.item()) == 0
+    ev.fill_(1)
     ops.advance_eval(ev)
     assert int(ev.item()) == 2
     mask = (torch.rand(B * N, generator=g(44)) > 0.5)
