@@ -50,7 +50,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI, int NSTAGE>
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int A_BYTES = BM * BK * 2;
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     else if (NSTAGE >= 3 && rem >= 1) wait_vm_lgkm0<LPT>();
     else wait_vm_lgkm0<0>();
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
-    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
+    if (DBG != 2 && kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
     const char* As = smem + buf * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < (DBG == 1 ? 0 : 2); ++kk) {
       bf16x8 xf[TM], wf[TN];
       const int c = kk * 4 + fq;
 #pragma unroll
@@ -242,6 +242,15 @@ int launch(GemmArgs& a, hipStream_t st) {
   return F5E_OK;
 }
 
+template <int EPI, int DBG>
+int launch_dbg(GemmArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + 63) / 64;
+  a.tiles_n = (a.N + 63) / 64;
+  hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, EPI, 3, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), 3 * 128 * 128, st, a);
+  F5E_LAUNCH_CHECK("gemm_bf16_dbg");
+  return F5E_OK;
+}
+
 // tile_hint: 0 = auto; otherwise tile + 10 * stages with tile 1 = 128x128, 2 = 128x64, 3 = 64x64 and stages in
 // {0 (default for the tile), 2, 3, 4}.
 template <int EPI>
@@ -265,6 +274,8 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     case 32: return launch<64, 64, EPI, 2>(a, st);
     case 33: return launch<64, 64, EPI, 3>(a, st);
     case 34: return launch<64, 64, EPI, 4>(a, st);
+    case 39: return launch_dbg<EPI, 1>(a, st);   // ablation: LDS-DMA ring + barriers only (results are garbage)
+    case 38: return launch_dbg<EPI, 2>(a, st);   // ablation: ds_read + MFMA + barriers only
     default:
       f5e_set_error("gemm_bf16: unknown tile_hint %d", tile_hint);
       return F5E_ERR_BAD_SHAPE;

@@ -1,0 +1,203 @@
+"""Multi-GPU batch inference driver (mirror of reference eval/eval_infer_batch.py:184-223 + the bucketing of
+eval/utils_eval.py:77-219), one process per GPU under ``torch.distributed`` (backend "nccl" = RCCL on ROCm).
+
+The path shards by utterance with NO data-path collective: RCCL carries only the start/stop barriers and
+one 16-byte all-reduce of (frames, seconds) -- weights are replicated, every rank writes its own wavs.  Differences
+from the reference that do not change any output file: each rank prepares only ITS share of the prompts (the
+reference prepares all prompts on every rank), and the default partition is longest-processing-time on the analytic
+FLOP cost instead of contiguous slices (``--partition contiguous`` restores the reference's
+``split_between_processes``).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import random
+import time
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+# ----------------------------------------------------------------------------- pure partition / bucketing logic
+
+def flop_fwd(n: int) -> float:
+    """Analytic FLOPs of one F5TTS_v1_Base DiT forward at N frames (SURVEY 8d / BASELINE.md section 3)."""
+    return 2.0 * (n * (189.44e6 + 45056.0 * n) + 141.8e6)
+
+
+def split_between_processes(items: Sequence, rank: int, world: int) -> List:
+    """HF accelerate semantics used at reference eval_infer_batch.py:187: contiguous slices, the first
+    ``len % world`` ranks get one extra item."""
+    n = len(items)
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    end = start + base + (1 if rank < extra else 0)
+    return list(items[start:end])
+
+
+def lpt_partition(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Greedy longest-processing-time assignment of item indices to ranks (ties broken by index: deterministic)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    parts: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(p) for p in parts]
+
+
+def bucket_batches(total_mel_lens: Sequence[int], infer_batch_size: int = 1, num_buckets: int = 200, min_secs: int = 3,
+                   max_secs: int = 40, target_sample_rate: int = 24000, hop_length: int = 256,
+                   shuffle_seed: int = 666) -> List[List[int]]:
+    """Index-level restatement of get_inference_prompt's batching (reference eval/utils_eval.py:96-219):
+    bucket = floor((len - min) / (max - min + 1) * num_buckets); a bucket is flushed once its accumulated frames
+    reach ``infer_batch_size``; residual buckets are flushed in bucket order; batches shuffled with seed 666."""
+    min_tokens = min_secs * target_sample_rate // hop_length
+    max_tokens = max_secs * target_sample_rate // hop_length
+    accum = [0] * num_buckets
+    pending: List[List[int]] = [[] for _ in range(num_buckets)]
+    batches: List[List[int]] = []
+    for i, n in enumerate(total_mel_lens):
+        if not (min_tokens <= n <= max_tokens):
+            raise ValueError(f"item {i}: {n} frames outside [{min_tokens}, {max_tokens}]")
+        b = math.floor((n - min_tokens) / (max_tokens - min_tokens + 1) * num_buckets)
+        pending[b].append(i)
+        accum[b] += n
+        if accum[b] >= infer_batch_size:
+            batches.append(pending[b])
+            pending[b], accum[b] = [], 0
+    for b in range(num_buckets):
+        if accum[b] > 0:
+            batches.append(pending[b])
+    rng = random.Random(shuffle_seed)  # same stream as random.seed(666); random.shuffle(...)
+    rng.shuffle(batches)
+    return batches
+
+
+def total_mel_len(ref_mel_len: int, prompt_text: str, gt_text: str, speed: float = 1.0) -> int:
+    """reference eval/utils_eval.py:147-161 (prompt_text already carries its trailing space rule)."""
+    return ref_mel_len + int(ref_mel_len / len(prompt_text.encode("utf-8")) * len(gt_text.encode("utf-8")) / speed)
+
+
+# ----------------------------------------------------------------------------- distributed driver
+
+def shard(items: Sequence, costs: Sequence[float], rank: int, world: int, mode: str = "lpt") -> List:
+    if mode == "contiguous":
+        return split_between_processes(items, rank, world)
+    return [items[i] for i in lpt_partition(costs, world)[rank]]
+
+
+def run_sharded(work: Sequence[Tuple[str, int, int]], process_one, rank: int, world: int, dist=None,
+                mode: str = "lpt") -> dict:
+    """``work``: (utt id, ref frames, total frames).  ``process_one(item)`` generates + writes one utterance.
+    Returns the whole-job totals after the closing all-reduce (works with any backend, incl. gloo on CPU)."""
+    mine = shard(list(work), [flop_fwd(w[2]) for w in work], rank, world, mode)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    frames = 0
+    for item in mine:
+        process_one(item)
+        frames += item[2]
+    elapsed = time.perf_counter() - t0
+    done = [w[0] for w in mine]
+    if dist is not None:
+        dist.barrier()
+        tot = torch.tensor([float(frames), elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            tot = tot.cuda()
+        f = tot.clone()
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        m = tot.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        frames, elapsed = float(f[0]), float(m[1])
+    return dict(frames=frames, seconds=elapsed, utts=done)
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="batch inference")
+    p.add_argument("-s", "--seed", default=None, type=int)
+    p.add_argument("-n", "--expname", required=True)
+    p.add_argument("-c", "--ckptstep", default=1250000, type=int)
+    p.add_argument("-nfe", "--nfestep", default=32, type=int)
+    p.add_argument("-o", "--odemethod", default="euler")
+    p.add_argument("-ss", "--swaysampling", default=-1, type=float)
+    p.add_argument("-t", "--testset", required=True, help="a .lst: ref_utt \\t ref_dur \\t ref_txt \\t gen_utt \\t gen_dur \\t gen_txt")
+    p.add_argument("--ckpt", default="", help="checkpoint file (default ckpts/<expname>/model_<ckptstep>.pt)")
+    p.add_argument("--audio_root", default="", help="directory with <ref_utt>.wav prompt audio (24 kHz)")
+    p.add_argument("--vocoder_path", default="pretrained_models/vocos-mel-24khz")
+    p.add_argument("--output_dir", default="")
+    p.add_argument("--partition", default="lpt", choices=["lpt", "contiguous"])
+    args = p.parse_args(argv)
+
+    import torch.distributed as dist
+
+    from ..infer import utils_infer as U
+    from ..infer.infer_cli import load_arch
+    from ..model import DiT
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    device = f"cuda:{local}"
+    ckpt = args.ckpt or f"ckpts/{args.expname}/model_{args.ckptstep}.pt"
+    model = U.load_model(DiT, load_arch(args.expname, ""), ckpt, ode_method=args.odemethod, device=device)
+    vocoder = U.load_vocoder("vocos", is_local=True, local_path=args.vocoder_path, device=device)
+    out_dir = args.output_dir or (f"results/{args.expname}_{args.ckptstep}/{os.path.basename(args.testset)}/"
+                                  f"seed{args.seed}_{args.odemethod}_nfe{args.nfestep}_vocos_ss{args.swaysampling}"
+                                  "_cfg2.0_speed1.0")
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+    rows = []
+    with open(args.testset, "r", encoding="utf-8") as f:
+        for line in f:
+            ref_utt, _rd, ref_txt, gen_utt, _gd, gen_txt = line.rstrip("\n").split("\t")
+            rows.append((ref_utt, ref_txt, gen_utt, gen_txt))
+    # cheap metadata pass (wav headers only) so that every rank can build the same partition without decoding audio
+    import wave
+    work, meta = [], {}
+    for ref_utt, ref_txt, gen_utt, gen_txt in rows:
+        path = os.path.join(args.audio_root, ref_utt + ".wav")
+        with wave.open(path, "rb") as w:
+            ref_len = w.getnframes() // U.hop_length
+        if len(ref_txt[-1].encode("utf-8")) == 1:
+            ref_txt = ref_txt + " "
+        work.append((gen_utt, ref_len, total_mel_len(ref_len, ref_txt, gen_txt)))
+        meta[gen_utt] = (path, ref_txt, gen_txt)
+
+    def process_one(item):
+        utt, ref_len, tot = item
+        path, ref_txt, gen_txt = meta[utt]
+        audio, sr = U.load_wav(path)
+        audio = audio.mean(0, keepdim=True)
+        rms = torch.sqrt(torch.mean(torch.square(audio)))
+        if rms < U.target_rms:
+            audio = audio * U.target_rms / rms
+        text = U.convert_char_to_pinyin([ref_txt + gen_txt])
+        with torch.inference_mode():
+            ref_mel = model.mel_spec(audio.to(device)).permute(0, 2, 1)[:, :ref_len]
+            gen, _ = model.sample(cond=ref_mel, text=text, duration=torch.tensor([tot]), lens=torch.tensor([ref_len]),
+                                  steps=args.nfestep, cfg_strength=2.0, sway_sampling_coef=args.swaysampling,
+                                  seed=args.seed)
+            wav = vocoder.decode(gen[:, ref_len:tot].permute(0, 2, 1).float())
+        if rms < U.target_rms:
+            wav = wav * rms / U.target_rms
+        U.save_wav(os.path.join(out_dir, f"{utt}.wav"), wav[0].cpu().numpy(), U.target_sample_rate)
+
+    res = run_sharded(work, process_one, rank, world, dist if world > 1 else None, args.partition)
+    if rank == 0:
+        print(f"Done batch inference in {res['seconds'] / 60:.2f} minutes: {res['frames'] / res['seconds']:.1f} "
+              f"mel-frames/s on {world} GPU(s).")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

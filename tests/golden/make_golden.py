@@ -162,7 +162,10 @@ def _install_shims():
 
     # tokeniser deps (not exercised) ---------------------------------------
     jb = types.ModuleType("jieba")
-    jb.cut = lambda s: list(s)
+    import re as _re
+    # jieba on single-byte text yields alphanumeric runs and single other characters (restated; unpinned third party)
+    jb.cut = lambda s: _re.findall(r"[A-Za-z0-9]+|.", s, _re.S)
+    jb.dt = types.SimpleNamespace(initialized=True)
     sys.modules["jieba"] = jb
     pp = types.ModuleType("pypinyin")
     pp.Style = types.SimpleNamespace(TONE3=0)
@@ -335,9 +338,95 @@ def make_prep_case(cfm_mod, dit_mod):
     print("wrote", path)
 
 
+def load_reference_infer(ref_root, cfm_mod):
+    """reference infer/utils_infer.py with its heavyweight imports shimmed (nothing in them is exercised)."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mpl = mod("matplotlib", use=lambda *a, **k: None)
+    mpl.pylab = mod("matplotlib.pylab")
+    mod("pydub", AudioSegment=object, silence=types.SimpleNamespace())
+    mod("vocos", Vocos=object)
+    mod("transformers", pipeline=lambda *a, **k: None)
+    mod("huggingface_hub", hf_hub_download=lambda *a, **k: None)
+    sys.modules["torchaudio"].load = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("shim"))
+    sys.modules["f5_tts.model"].CFM = cfm_mod.CFM
+    pkg = types.ModuleType("f5_tts.infer")
+    pkg.__path__ = [os.path.join(ref_root, "src", "f5_tts", "infer")]
+    sys.modules["f5_tts.infer"] = pkg
+    return importlib.import_module("f5_tts.infer.utils_infer")
+
+
+def make_callers_case(ref_root, cfm_mod):
+    """Callers of the path: chunk_text, process_batch's duration / slice / RMS / cross-fade
+    rules and load_checkpoint's key handling, captured from the reference with recording stubs."""
+    import json
+    U = load_reference_infer(ref_root, cfm_mod)
+    out = {"chunk_text": [], "batch": []}
+    for text, mc in (("Hello there. This is a test, of chunking; really! Yes? Ok: fine.", 24),
+                     ("One sentence only", 135), ("A. B. C. D. E. F. G.", 5),
+                     ("No punctuation here at all just words going on and on", 20)):
+        out["chunk_text"].append({"text": text, "max_chars": mc, "chunks": U.chunk_text(text, max_chars=mc)})
+
+    class Model:
+        def __init__(self):
+            self.calls = []
+
+        def sample(self, **kw):
+            self.calls.append({k: (v if not isinstance(v, torch.Tensor) else list(v.shape)) for k, v in kw.items()})
+            return torch.zeros(1, kw["duration"], 100), None
+
+    class Voc:
+        def decode(self, mel):
+            n = 256 * (mel.shape[-1] - 1)
+            return (torch.arange(n, dtype=torch.float32)[None] % 97) / 97.0 - 0.5
+
+    g = torch.Generator().manual_seed(21)
+    for nw, amp, ref_text, gens, speed, fixd, xf in (
+            (24000 * 2 + 100, 0.02, "Reference text here.", ["Short.", "A somewhat longer piece of generated text."], 1.0, None, 0.15),
+            (24000 * 3, 0.5, "Another reference", ["Tiny", "Medium sized chunk of words", "And a third chunk to fade."], 1.3, None, 0.05),
+            (24000 * 2, 0.05, "Fixed duration case.", ["Whatever text."], 1.0, 6.5, 0.0)):
+        audio = amp * torch.randn(2, nw, generator=g)
+        m = Model()
+        wave_, sr, spec = next(U.infer_batch_process((audio, 24000), ref_text, gens, m, Voc(), progress=None,
+                                                     cross_fade_duration=xf, speed=speed, fix_duration=fixd,
+                                                     device="cpu"))
+        out["batch"].append({"nw": nw, "amp": amp, "seed_note": "audio = amp * randn(2, nw, generator seeded 21, in order)",
+                             "ref_text": ref_text, "gens": gens, "speed": speed, "fix_duration": fixd, "cross_fade": xf,
+                             "durations": [c["duration"] for c in m.calls],
+                             "cond_shapes": [c["cond"] for c in m.calls],
+                             "wave_len": int(len(wave_)), "wave_sum": float(np.sum(wave_)),
+                             "wave_abs_sum": float(np.abs(wave_).sum()), "wave_head": [float(x) for x in wave_[:8]],
+                             "spec_shape": list(spec.shape)})
+    # load_checkpoint key handling
+    import tempfile
+    lin = nn.Linear(3, 2)
+    sd = {"ema_model." + k: v.clone() + 1 for k, v in lin.state_dict().items()}
+    sd.update({"initted": torch.tensor(True), "step": torch.tensor(5),
+               "ema_model.mel_spec.mel_stft.mel_scale.fb": torch.zeros(2),
+               "ema_model.mel_spec.mel_stft.spectrogram.window": torch.zeros(2)})
+    with tempfile.TemporaryDirectory() as d:
+        pth = os.path.join(d, "m.pt")
+        torch.save({"ema_model_state_dict": sd}, pth)
+        loaded = U.load_checkpoint(nn.Linear(3, 2), pth, "cpu", dtype=torch.float32, use_ema=True)
+    out["load_checkpoint"] = {"in_keys": sorted(sd.keys()), "loaded_keys": sorted(loaded.state_dict().keys()),
+                              "weight_delta": float((loaded.weight - lin.weight).mean())}
+    path = os.path.join(HERE, "callers.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     modules_mod, dit_mod, cfm_mod, utils_mod = load_reference(ref)
+    if len(sys.argv) > 2 and sys.argv[2] == "callers":
+        make_callers_case(ref, cfm_mod)
+        return
     small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
                  conv_layers=2)
     make_dit_case(dit_mod, cfm_mod, "b1", small, b=1, n=48, nc=17, nt=9, steps=4, cfg_strength=2.0, seed=100)
@@ -350,6 +439,7 @@ def main():
     make_dit_case(dit_mod, cfm_mod, "b1_ppg_vc", pe, b=1, n=40, nc=15, nt=10, steps=2, cfg_strength=2.0, seed=500,
                   n_ppg=21, mode="vc")
     make_prep_case(cfm_mod, dit_mod)
+    make_callers_case(ref, cfm_mod)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,268 @@
+"""CPU-side tests: the C-ABI library loads and exports what include/f5e_abi.h declares; the module mirrors keep the
+reference's state_dict layout; caller mirrors (chunking, duration/RMS/cross-fade rules, checkpoint loading, CLI flag
+merge, bucketing/sharding) match fixtures captured from the reference; the product path fails loudly without a GPU.
+No kernel is launched here."""
+import ast
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ C ABI
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "f5e_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(f5e_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from f5e_tts_amd import _C
+    lib = _C.lib()
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in f5e_abi.h but not exported"
+        assert n in _C.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.f5e_abi_version() == 1
+    assert lib.f5e_last_error() == b""
+
+
+def test_abi_rejects_bad_shapes_without_launching():
+    import ctypes as C
+    from f5e_tts_amd import _C
+    lib = _C.lib()
+    rc = lib.f5e_gemm_bf16_bias(None, C.c_void_p(8), 64, C.c_void_p(8), 64, None, C.c_void_p(8), 64, 4, 4, 60, 0, 0, 0)
+    assert rc == -1 and b"multiple of 64" in lib.f5e_last_error()
+    rc = lib.f5e_layernorm(None, C.c_void_p(8), 100, C.c_void_p(8), 100, 1, None, None, None, None, 0, 0, 1, None, 0, 4,
+                           100, 1e-6)
+    assert rc == -1 and b"multiple of 256" in lib.f5e_last_error()
+    rc = lib.f5e_flash_attn(None, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1024, None, 1, 16, 100,
+                            100, 0)
+    assert rc == -1 and b"n_pad" in lib.f5e_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from f5e_tts_amd import _C, ops
+    from f5e_tts_amd.model import CFM, DiT, MelSpec
+    with pytest.raises(_C.F5EError):
+        ops.require_device()
+    with pytest.raises(_C.F5EError):
+        MelSpec()(torch.zeros(1, 4096))
+    dit = DiT(dim=1024, depth=1, heads=16, ff_mult=2, text_dim=256, conv_layers=1, text_num_embeds=30)
+    with pytest.raises(_C.F5EError):
+        dit.sample(torch.zeros(1, 8, 100), torch.zeros(1, 8, 100), None, None, torch.tensor(0.5), False, False, False)
+    with pytest.raises(_C.F5EError):
+        CFM(transformer=dit).sample(torch.zeros(1, 8, 100), torch.zeros(1, 3, dtype=torch.long), duration=16, steps=2)
+    with pytest.raises(NotImplementedError):
+        dit(torch.zeros(1))
+
+
+def test_no_product_import_of_oracle():
+    pkg = os.path.join(ROOT, "f5e-tts_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|f5e_oracle|oracle/", src, flags=re.M), \
+                    f"{f} imports / links the oracle"
+
+
+# ------------------------------------------------------------------ state_dict layout
+
+@pytest.mark.parametrize("tag", ["b1", "b2_ppg_tts"])
+def test_state_dict_layout_matches_reference(tag):
+    from f5e_tts_amd.model import DiT
+    z = np.load(os.path.join(GOLD, f"dit_{tag}.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    ref = {k[2:]: z[k].shape for k in z.files if k.startswith("w/")}
+    ppg = dict(use_ppg=meta["n_ppg"] > 0, ppg_dim=32, use_transformer=False)
+    m = DiT(dim=meta["dim"], depth=meta["depth"], heads=meta["heads"], dim_head=64, ff_mult=meta["ff_mult"],
+            mel_dim=meta["mel_dim"], text_num_embeds=meta["text_num_embeds"], text_dim=meta["text_dim"],
+            conv_layers=meta["conv_layers"], qk_norm=meta.get("qk_norm"), pe_attn_head=meta.get("pe_attn_head"),
+            long_skip_connection=meta.get("long_skip_connection", False),
+            text_mask_padding=meta.get("text_mask_padding", True), ppg_config=ppg)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == {k: tuple(v) for k, v in ref.items()}
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}, strict=True)
+
+
+def test_v1_base_layout_and_zero_init():
+    from f5e_tts_amd.model import DiT
+    m = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
+    sd = m.state_dict()
+    assert len(sd) == 364 and sum(p.numel() for p in m.parameters()) == 337096804
+    assert sd["input_embed.proj.weight"].shape == (1024, 712)
+    assert float(sd["proj_out.weight"].abs().max()) == 0 and float(sd["transformer_blocks.3.attn_norm.linear.bias"].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ callers vs reference fixtures
+
+def callers():
+    return json.load(open(os.path.join(GOLD, "callers.json")))
+
+
+def test_chunk_text_matches_reference():
+    from f5e_tts_amd.infer.utils_infer import chunk_text
+    for case in callers()["chunk_text"]:
+        assert chunk_text(case["text"], max_chars=case["max_chars"]) == case["chunks"]
+
+
+def test_infer_batch_process_rules_match_reference():
+    from f5e_tts_amd.infer import utils_infer as U
+
+    class Model:
+        def __init__(self):
+            self.calls = []
+
+        def sample(self, **kw):
+            self.calls.append(kw)
+            return torch.zeros(1, kw["duration"], 100), None
+
+    class Voc:
+        def decode(self, mel):
+            n = 256 * (mel.shape[-1] - 1)
+            return (torch.arange(n, dtype=torch.float32)[None] % 97) / 97.0 - 0.5
+
+    g = torch.Generator().manual_seed(21)
+    for case in callers()["batch"]:
+        audio = case["amp"] * torch.randn(2, case["nw"], generator=g)
+        m = Model()
+        wave, sr, spec = next(U.infer_batch_process((audio, 24000), case["ref_text"], case["gens"], m, Voc(),
+                                                    cross_fade_duration=case["cross_fade"], speed=case["speed"],
+                                                    fix_duration=case["fix_duration"], device="cpu"))
+        assert [c["duration"] for c in m.calls] == case["durations"]
+        assert [list(c["cond"].shape) for c in m.calls] == case["cond_shapes"]
+        assert all(c["steps"] == 32 and c["cfg_strength"] == 2.0 and c["sway_sampling_coef"] == -1 for c in m.calls)
+        assert len(wave) == case["wave_len"] and list(spec.shape) == case["spec_shape"]
+        np.testing.assert_allclose(wave[:8], case["wave_head"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(float(np.sum(wave)), case["wave_sum"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(float(np.abs(wave).sum()), case["wave_abs_sum"], rtol=1e-5)
+
+
+def test_ascii_tokeniser_and_duration_rule():
+    from f5e_tts_amd.infer.utils_infer import convert_char_to_pinyin, plan_batch
+    assert convert_char_to_pinyin(["end.Next one;ok"]) == [list("end. Next one, ok")]
+    assert convert_char_to_pinyin(["it's 2 fast"]) == [list("it's 2 fast")]
+    assert plan_batch(187, "Some call me nature. ", "Hi.", 1.0, None) == (187 + int(187 / 21 * 3 / 0.3), 0.3)
+    assert plan_batch(100, "abcd", "x" * 40, 2.0, None) == (100 + int(100 / 4 * 40 / 2.0), 2.0)
+    assert plan_batch(100, "abcd", "x" * 40, 1.0, 6.5)[0] == int(6.5 * 24000 / 256)
+
+
+@pytest.mark.parametrize("ext", ["pt", "safetensors"])
+def test_load_checkpoint_matches_reference_key_handling(tmp_path, ext):
+    from f5e_tts_amd.infer.utils_infer import load_checkpoint
+    ref = callers()["load_checkpoint"]
+    lin = torch.nn.Linear(3, 2)
+    sd = {"ema_model." + k: v.detach().clone() + 1 for k, v in lin.state_dict().items()}
+    sd.update({"ema_model.mel_spec.mel_stft.mel_scale.fb": torch.zeros(2),
+               "ema_model.mel_spec.mel_stft.spectrogram.window": torch.zeros(2)})
+    path = str(tmp_path / f"m.{ext}")
+    if ext == "pt":
+        sd.update({"initted": torch.tensor(True), "step": torch.tensor(5)})
+        assert sorted(sd) == ref["in_keys"]
+        torch.save({"ema_model_state_dict": sd}, path)
+    else:
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    loaded = load_checkpoint(torch.nn.Linear(3, 2), path, "cpu", use_ema=True)
+    assert sorted(loaded.state_dict()) == ref["loaded_keys"]
+    assert abs(float((loaded.weight - lin.weight).mean()) - ref["weight_delta"]) < 1e-6
+
+
+def test_cli_flag_merge_precedence_and_falsy_quirk():
+    """flag > toml > default; falsy flag values fall through (reference infer_cli.py:181-211, restated from the source
+    text: the module executes at import time, so it cannot be imported to capture fixtures)."""
+    from f5e_tts_amd.infer.infer_cli import build_parser, resolve_settings, split_voices
+    P = build_parser()
+    s = resolve_settings(P.parse_args([]), {})
+    assert (s["model"], s["nfe_step"], s["cfg_strength"], s["sway_sampling_coef"], s["speed"]) == \
+        ("F5TTS_v1_Base", 32, 2.0, -1.0, 1.0)
+    assert s["target_rms"] == 0.1 and s["cross_fade_duration"] == 0.15 and s["fix_duration"] is None
+    s = resolve_settings(P.parse_args(["--nfe_step", "16", "-t", "hi"]), {"nfe_step": 8, "speed": 1.5, "gen_text": "toml"})
+    assert s["nfe_step"] == 16 and s["speed"] == 1.5 and s["gen_text"] == "hi"
+    s = resolve_settings(P.parse_args(["--cfg_strength", "0", "--sway_sampling_coef", "0"]), {"cfg_strength": 3.0})
+    assert s["cfg_strength"] == 3.0 and s["sway_sampling_coef"] == -1.0       # falsy flags fall through
+    s = resolve_settings(P.parse_args(["-s", ""]), {"ref_text": "from toml"})
+    assert s["ref_text"] == ""                                                   # ref_text uses `is not None`
+    assert split_voices("[main] Hello. [town] Hi there. plain") == [("main", "Hello."), ("town", "Hi there. plain")]
+    assert split_voices("no tags") == [("main", "no tags")]
+    flags = {a.option_strings[-1] for a in P._actions}
+    for f in ("--config", "--model", "--model_cfg", "--ckpt_file", "--vocab_file", "--ref_audio", "--ref_text",
+              "--gen_text", "--gen_file", "--output_dir", "--output_file", "--save_chunk", "--remove_silence",
+              "--load_vocoder_from_local", "--vocoder_name", "--target_rms", "--cross_fade_duration", "--nfe_step",
+              "--cfg_strength", "--sway_sampling_coef", "--speed", "--fix_duration", "--device"):
+        assert f in flags
+
+
+def test_arch_config_and_vocab():
+    from f5e_tts_amd.infer.infer_cli import load_arch
+    from f5e_tts_amd.model.utils import get_tokenizer, list_str_to_idx
+    arch = load_arch("F5TTS_v1_Base", "")
+    assert arch == dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=True, qk_norm=None,
+                        conv_layers=4, pe_attn_head=None)
+    vocab, size = get_tokenizer(os.path.join(ROOT, "f5e-tts_amd", "infer", "examples", "vocab.txt"))
+    assert size == 2545 and vocab[" "] == 0
+    ids = list_str_to_idx([list("ab c"), list("a")], vocab)
+    assert ids.shape == (2, 4) and ids[1, 1:].tolist() == [-1, -1, -1] and ids[0, 2] == 0
+
+
+# ------------------------------------------------------------------ bucketing / sharding
+
+def test_bucketing_and_partitions():
+    from f5e_tts_amd.eval.eval_infer_batch import (bucket_batches, flop_fwd, lpt_partition, split_between_processes,
+                                                    total_mel_len)
+    assert abs(flop_fwd(469) / 1e9 - 197.8) < 0.1 and abs(flop_fwd(938) / 1e9 - 435.0) < 0.2
+    items = list(range(11))
+    parts = [split_between_processes(items, r, 4) for r in range(4)]
+    assert parts == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10]]
+    lens = [300 + (37 * i) % 3000 for i in range(97)]
+    b1 = bucket_batches(lens, infer_batch_size=1)
+    assert sorted(i for b in b1 for i in b) == list(range(97)) and all(len(b) == 1 for b in b1)
+    assert b1 == bucket_batches(lens, infer_batch_size=1)              # seed-666 shuffle is deterministic
+    b2 = bucket_batches(lens, infer_batch_size=4000)
+    assert sorted(i for b in b2 for i in b) == list(range(97)) and max(len(b) for b in b2) > 1
+    with pytest.raises(ValueError):
+        bucket_batches([100])
+    costs = [flop_fwd(n) for n in lens]
+    lp = lpt_partition(costs, 8)
+    assert sorted(i for p in lp for i in p) == list(range(97))
+    loads = [sum(costs[i] for i in p) for p in lp]
+    assert max(loads) / (sum(loads) / 8) < 1.05                         # near-perfect balance
+    assert total_mel_len(187, "Some call me nature. ", "Hello world") == 187 + int(187 / 21 * 11)
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from f5e_tts_amd.eval.eval_infer_batch import run_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    work = [(f"utt{i}", 100 + i, 300 + 53 * (i % 7)) for i in range(13)]
+    done = []
+    res = run_sharded(work, lambda item: done.append(item[0]), rank, world, dist)
+    with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+        json.dump(dict(done=done, frames=res["frames"], seconds=res["seconds"]), f)
+    dist.destroy_process_group()
+
+
+def test_sharded_driver_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [json.load(open(tmp_path / f"r{i}.json")) for i in range(2)]
+    all_done = sorted(r[0]["done"] + r[1]["done"])
+    assert all_done == sorted(f"utt{i}" for i in range(13)) and not set(r[0]["done"]) & set(r[1]["done"])
+    total = sum(300 + 53 * (i % 7) for i in range(13))
+    assert r[0]["frames"] == r[1]["frames"] == total                   # SUM all-reduce
+    assert r[0]["seconds"] == r[1]["seconds"] > 0                      # MAX all-reduce
