@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_REF, N_TOTAL, NFE, CFG, SWAY = 188, 469, 32, 2.0, -1.0
+BATCH = 1
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
 
 
@@ -55,7 +56,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3"],
+                    help="C2 (default, the graded line): batch 1, 2 s ref / 5 s total; C3: batch 32, 4 s / 10 s")
     args = ap.parse_args()
+    global N_REF, N_TOTAL, BATCH
+    if args.workload == "C3":
+        N_REF, N_TOTAL, BATCH = 375, 938, 32
 
     import torch
     import torch.distributed as dist
@@ -86,8 +92,8 @@ def main():
     voc = Vocos()
     voc.load_state_dict(vs, strict=False)
     voc = voc.cuda().eval()
-    wav = O.synthetic_ref_wave(N_REF).cuda()
-    text = O.synthetic_text_ids(N_TOTAL).cuda()
+    wav = O.synthetic_ref_wave(N_REF, batch=BATCH).cuda()
+    text = O.synthetic_text_ids(N_TOTAL, batch=BATCH).cuda()
 
     def one_pass():
         mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
@@ -116,18 +122,19 @@ def main():
         elapsed = float(tt.item())
 
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
-    frames = world * args.steps * N_TOTAL
-    gen_audio_s = world * args.steps * (N_TOTAL - N_REF) * 256 / 24000.0
+    frames = world * args.steps * N_TOTAL * BATCH
+    gen_audio_s = world * args.steps * BATCH * (N_TOTAL - N_REF) * 256 / 24000.0
     value = frames / elapsed
 
     roofline = None
     if rank == 0 and not args.no_roofline:
         # in-situ per-launch timing: eager launches of the SAME kernels in the SAME order, one op class at a time
-        M = 2 * N_TOTAL
+        n_chains = getattr(dit.engine(), "last_n_chains", 1)
+        M = 2 * N_TOTAL * BATCH // n_chains          # rows per launch (the CFG branches may run as parallel chains)
         cfm.use_graph = False
         per_op = {}
         for name, op in (("QKV", OP_QKV), ("OUT", OP_OUT), ("FF1", OP_FF1), ("FF2", OP_FF2)):
-            tm = KernelTimer(op, capacity=NFE * 22 + 8)
+            tm = KernelTimer(op, capacity=NFE * 22 * n_chains + 8)
             cfm.kernel_timer = tm
             one_pass()
             torch.cuda.synchronize()
@@ -144,11 +151,11 @@ def main():
                     "kernel": {"QKV": "gemm_bf16_kernel<*,*,EPI_QKV_ROPE>", "OUT": "gemm_bf16_kernel<*,*,EPI_GATE_RES>",
                                "FF1": "gemm_bf16_kernel<*,*,EPI_BF16_GELU>", "FF2": "gemm_bf16_kernel<*,*,EPI_GATE_RES>"}[dom],
                     "op": dom, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": per_op[dom][1],
-                    "flop_per_launch": gemm_flops(dom, M),
+                    "flop_per_launch": gemm_flops(dom, M), "rows_per_launch": M, "parallel_chains": n_chains,
                     "all_gemm_avg_us": {k: round(v[0] * 1e3, 2) for k, v in per_op.items()}}
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "C2":
         sample_steps = 2
         torch.set_num_threads(host_threads())
         log(f"cpu baseline on {torch.get_num_threads()} threads")
@@ -175,13 +182,13 @@ def main():
             "metric": "mel_frames_per_sec", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"C2: F5TTS_v1_Base random-init, batch 1 per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
+            "config": {"workload": f"{args.workload}: F5TTS_v1_Base random-init, batch {BATCH} per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
                                    f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE step, "
                                    "HIP log-mel front-end + Vocos decode on GPU",
-                       "frames_per_step": N_TOTAL, "parallelism": f"replica x{world} (utterance sharding, no collective "
+                       "frames_per_step": N_TOTAL * BATCH, "parallelism": f"replica x{world} (utterance sharding, no collective "
                                                                   "on the data path)"},
             "rtf": round(elapsed / gen_audio_s, 5),
-            "generated_mel_frames_per_sec": round(world * args.steps * (N_TOTAL - N_REF) / elapsed, 2),
+            "generated_mel_frames_per_sec": round(world * args.steps * BATCH * (N_TOTAL - N_REF) / elapsed, 2),
         }
         if roofline is not None:
             line["roofline"] = roofline

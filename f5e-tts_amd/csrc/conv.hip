@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
       glds16c(w_src[j] + (size_t)tap * 4096, Wsb + buf * W_BYTES + (wave * 64 + 256 * j) * 16);
   };
   stage_w(0, 0);
+  stage_w(1, 1);
 
   // activation tile with halo (register staged: needs zero fill)
   for (int i = tid; i < XR * 8; i += 256) {
@@ -81,11 +82,13 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // 3-stage LDS-DMA ring over the 31 taps: two weight tiles in flight, counted vmcnt + raw barrier (as gemm_bf16.hip)
+  int buf = 0, nbuf = 2;
   for (int tap = 0; tap < 31; ++tap) {
-    const int buf = tap & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tap + 1 < 31) stage_w(buf ^ 1, tap + 1);
+    if (tap < 30) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tap + 2 < 31) stage_w(nbuf, tap + 2);
     const char* Ws = Wsb + buf * W_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -107,6 +110,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    buf = (buf == 2) ? 0 : buf + 1;
+    nbuf = (nbuf == 2) ? 0 : nbuf + 1;
   }
 
 #pragma unroll
@@ -189,7 +194,7 @@ int f5e_convpos(hipStream_t st, const void* x, int ldx, const void* w_packed, co
   a.S = S; a.N = N; a.D = D; a.mode = mode;
   a.tiles_t = (N + 63) / 64;
   const int grid = a.tiles_t * (D / 64) * S;
-  const int lds = ((94 * 128 + 255) & ~255) + 2 * 8192;
+  const int lds = ((94 * 128 + 255) & ~255) + 3 * 8192;
   hipLaunchKernelGGL(convpos_kernel, dim3(grid), dim3(256), lds, st, a);
   F5E_LAUNCH_CHECK("convpos");
   return F5E_OK;

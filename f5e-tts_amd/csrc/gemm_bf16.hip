@@ -113,6 +113,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Epilogue operands are fetched NOW so their (cold-cache) latency hides under the K loop: bias always, and for the
+  // gated-residual epilogue also the gate row and the fp32 residual tile.  Only for small tiles (register budget).
+  constexpr bool PREF = (TM * TN <= 4);
+  f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
+  bool pf_live[PREF ? TM : 1];
+  if (PREF) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn0 + i * 16 + fq * 4;
+      pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (EPI == EPI_GATE_RES) {
+      const size_t eoff = a.eval_ptr ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm0 + j * 16 + fr;
+        const int seq = m / a.rows_per_seq, pos = m - seq * a.rows_per_seq;
+        pf_live[j] = (m < a.M) && ((a.seq_len == nullptr) || (pos < a.seq_len[seq]));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int n = n0 + wn0 + i * 16 + fq * 4;
+          const bool ok = pf_live[j] && n < a.N;
+          pf_gate[i][j] = ok ? *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+          pf_x[i][j] = ok ? *(const f32x4*)(a.resid + (size_t)m * a.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+
   // NSTAGE-deep LDS ring fed by LDS-DMA: NSTAGE-1 K-tiles are in flight while one is consumed.  Counted vmcnt +
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
@@ -169,7 +199,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
       const int n = n0 + wn0 + i * 16 + fq * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
-      if (a.bias) {
+      if (PREF) {
+        v += pf_bias[i];
+      } else if (a.bias) {
         const f32x4 b = *(const f32x4*)(a.bias + n);
         v += b;
       }
@@ -180,6 +212,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
             f2bf4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
       } else if (EPI == EPI_F32) {
         *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
+      } else if (EPI == EPI_GATE_RES && PREF) {
+        if (pf_live[j]) *(f32x4*)(a.resid + (size_t)m * a.ldr + n) = pf_x[i][j] + pf_gate[i][j] * v;
       } else if (EPI == EPI_GATE_RES) {
         const bool live = (a.seq_len == nullptr) || (pos < a.seq_len[seq]);
         if (live) {
@@ -264,7 +298,8 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     else if (blocks(128, 64) >= 512) sel = 2;
     else sel = 3;
   }
-  if (ns == 0) ns = 3;
+  // stages: 128x128 wants 2 (64 KiB LDS -> 2 workgroups per CU; measured 386 vs 556 us at M = 60k), small tiles 3
+  if (ns == 0) ns = (sel == 1) ? 2 : 3;
   switch (sel * 10 + ns) {
     case 12: return launch<128, 128, EPI, 2>(a, st);
     case 13: return launch<128, 128, EPI, 3>(a, st);

@@ -281,7 +281,7 @@ class DiTEngine:
     # ------------------------------------------------------------------ plan / workspace
 
     def make_plan(self, S: int, B: int, N: int, y: Tensor, in_const: Tensor, mod: Tensor, eval_ptr: Optional[Tensor],
-                  rope_cs: Tensor, seq_len: Optional[Tensor]) -> "_Plan":
+                  rope_cs: Tensor, seq_len: Optional[Tensor], pred: Optional[Tensor] = None) -> "_Plan":
         cfg, dv = self.cfg, self.device
         D, H, mel = cfg.dim, cfg.heads, cfg.mel_dim
         n_pad = (N + 63) // 64 * 64
@@ -293,7 +293,7 @@ class DiTEngine:
             q=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF), k=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF),
             vt=torch.zeros(S, H, 64, n_pad, device=dv, dtype=BF),
             ao=torch.empty(M, self.inner, device=dv, dtype=BF), ff=torch.empty(M, self.FF, device=dv, dtype=BF),
-            pred=torch.empty(M, mel, device=dv))
+            pred=pred if pred is not None else torch.empty(M, mel, device=dv))
         p = _C.DitPlan()
         p.S, p.B, p.N, p.n_pad, p.D, p.H = S, B, N, n_pad, D, H
         p.rope_heads, p.FF, p.L, p.mel, p.mod_rows = self.rope_heads, self.FF, self.L, mel, mod.shape[1]
@@ -374,7 +374,7 @@ class KernelTimer:
 
 
 def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
-            timer: Optional[KernelTimer] = None) -> Tensor:
+            timer: Optional[KernelTimer] = None, chains: Optional[int] = None) -> Tensor:
     """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint).
 
     Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
@@ -427,23 +427,64 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     y = inp.y0.detach().clone().contiguous()
     y_mid = torch.empty_like(y) if eps_per_step == 2 else None
 
-    plan_a = engine.make_plan(S, B, N, y, in_const, mod, eval_ptr, rope_cs, seq_len)
-    plan_b = engine.make_plan(S, B, N, y_mid, in_const, mod, eval_ptr, rope_cs, seq_len) if y_mid is not None else None
+    # Chains: at small batch a step is bound by the latency of ~160 dependent launches, not by MFMA or HBM, so the
+    # CFG branches (independent until the combine) run as PARALLEL chains of the captured graph and their fixed
+    # per-kernel costs overlap; weights are then read once per branch instead of once per step (L2/MALL absorb most
+    # of it at these sizes).  At larger batch the branches stay batched in one forward so weights stream once.
+    n_chains = nb if (chains is None and nb > 1 and S * N <= 4096) else (chains or 1)
+    if nb % n_chains:
+        raise _C.F5EError(f"chains={n_chains} must divide the number of CFG branches {nb}")
+    per = nb // n_chains  # branches per chain
+    engine.last_n_chains = n_chains
+    pred_all = torch.empty(S * N, mel, device=dv)
+
+    def plans_for(y_in):
+        out = []
+        for c in range(n_chains):
+            lo, hi = c * per * B * N, (c + 1) * per * B * N
+            sl = seq_len[c * per * B:(c + 1) * per * B].contiguous() if seq_len is not None else None
+            out.append(engine.make_plan(per * B, B, N, y_in, in_const[lo:hi], mod, eval_ptr, rope_cs, sl,
+                                        pred=pred_all[lo:hi]))
+        return out
+
+    plans_a = plans_for(y)
+    plans_b = plans_for(y_mid) if y_mid is not None else None
     if timer is not None:
         if use_graph:
             raise _C.F5EError("KernelTimer brackets eager launches only (use_graph=False)")
-        for pl in (plan_a, plan_b):
-            if pl is not None:
-                pl.c.timer, pl.c.timer_op = timer.handle, timer.op
+        for pl in plans_a + (plans_b or []):
+            pl.c.timer, pl.c.timer_op = timer.handle, timer.op
+
+    aux_streams = [torch.cuda.Stream(device=dv) for _ in range(n_chains - 1)] if use_graph else []
+
+    def forward_all(plans):
+        if not aux_streams:
+            for pl in plans:
+                engine.forward(pl)
+            return
+        main = torch.cuda.current_stream(dv)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for pl, st in zip(plans[1:], aux_streams):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                engine.forward(pl)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            joins.append(ev)
+        engine.forward(plans[0])
+        for ev in joins:
+            main.wait_event(ev)
 
     def one_step(traj_row: Optional[Tensor]):
-        engine.forward(plan_a)
+        forward_all(plans_a)
         if eps_per_step == 1:
-            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
+            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
         else:
-            ops.ode_update(plan_a.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None, done)
-            engine.forward(plan_b)
-            ops.ode_update(plan_b.ws["pred"], n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
+            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None, done)
+            forward_all(plans_b)
+            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
 
     if use_graph and steps > 1:
         gr = ops.Graph()

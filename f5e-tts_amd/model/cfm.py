@@ -46,6 +46,7 @@ class CFM(nn.Module):
         self.use_codebook = cb_config["use_codebook"]
         self.use_align_loss = cb_config.get("use_align_loss", False)
         self.use_graph = True  # hipGraph replay of the ODE step; set False to launch eagerly (debugging)
+        self.chains = None  # None = auto (parallel CFG-branch chains at small batch); 1 = always one batched forward
         self.kernel_timer = None  # engine.KernelTimer: per-launch HIP-event timing of one op class (eager mode only)
         self._side_stream = None
 
@@ -132,10 +133,10 @@ class CFM(nn.Module):
             side = self._side_stream
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                trajectory = run_ode(eng, inp, use_graph=True)
+                trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains)
             cur.wait_stream(side)
         else:
-            trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer)
+            trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)
         self.transformer.clear_cache()
         out = torch.empty_like(trajectory[-1])
         from .. import ops

@@ -9,7 +9,7 @@ from f5e_tts_amd import ops
 BF = torch.bfloat16
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 938
 rps = M // 2
-NW = 48
+NW = int(os.environ.get("NW", "48"))
 def timeit(fn, reps=NW * 2):
     for i in range(NW): fn(i)
     torch.cuda.synchronize()
