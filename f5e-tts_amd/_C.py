@@ -18,12 +18,12 @@ SIGNATURES = {
     "f5e_check_device": [],
     "f5e_gemm_bf16_bias": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "f5e_gemm_bf16_gate_residual": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I],
-    "f5e_gemm_bf16_qkv_rope": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I],
+    "f5e_gemm_bf16_qkv_rope": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I],
     "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
     "f5e_grn": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
-    "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I],
+    "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
     "f5e_sinus_embed": [_P, _P, _P, _P, _I, _I, _F],
@@ -49,16 +49,18 @@ _RESTYPE = {"f5e_last_error": C.c_char_p}
 
 
 class BlockWeights(C.Structure):
-    _fields_ = [(n, _P) for n in ("w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2")]
+    _fields_ = [(n, _P) for n in ("w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+                                  "q_norm_w", "k_norm_w")]
 
 
 class DitPlan(C.Structure):
     _fields_ = (
         [(n, _I) for n in ("S", "B", "N", "n_pad", "D", "H", "rope_heads", "FF", "L", "mel", "mod_rows")]
         + [("y", _P), ("w_x", _P), ("ldw_x", _I), ("in_const", _P)]
-        + [(n, _P) for n in ("convpos_w1", "convpos_b1", "convpos_w2", "convpos_b2", "rope_cs", "seq_len", "mod",
-                             "eval_ptr")]
+        + [(n, _P) for n in ("convpos_w1", "convpos_b1", "convpos_w2", "convpos_b2")] + [("convpos_groups", _I)]
+        + [(n, _P) for n in ("rope_cs", "seq_len", "mod", "eval_ptr")]
         + [("blocks", C.POINTER(BlockWeights)), ("w_proj", _P), ("b_proj", _P)]
+        + [("w_skip", _P), ("skip_res", _P), ("skip_tmp", _P)]
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
         + [("timer", _P), ("timer_op", _I)]
     )

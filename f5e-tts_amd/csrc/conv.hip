@@ -1,10 +1,12 @@
 // 1-D convolutions on the hot path.
 //
-// f5e_convpos: one grouped Conv1d(D, D, k=31, groups=D/64, pad=15) + Mish of ConvPositionEmbedding
+// f5e_convpos: one grouped Conv1d(D, D, k=31, groups=G, pad=15) + Mish of ConvPositionEmbedding
 //   (reference model/modules.py:167-190, called WITHOUT a mask at backbones/dit.py:176) as an implicit GEMM on
 //   v_mfma_f32_16x16x32_bf16: per (sequence, group, 64-token tile) the K dimension is (tap, in-channel) = 31 x 64;
 //   the activation tile with its 15-frame halo is staged into LDS once and every tap is just a row offset into it,
-//   the per-tap weight tile [64 oc][64 ic] streams through a 2-stage LDS-DMA ring.  Rows outside [0, N) are zeros
+//   the per-tap weight tile [64 oc][64 ic] streams through a 3-stage LDS-DMA ring.  Groups narrower than 64 channels
+//   (cpg = D/G in {16, 32, 48, 64}) use the same 64 x 64 tile with zero-padded weights: the extra input channels
+//   read the neighbouring group's data against zero weights, the extra output channels are not stored.  Rows outside [0, N) are zeros
 //   (the Conv1d zero padding); rows between a short item's length and N are real data, exactly as in the reference.
 //   mode 0: out_bf16 = mish(conv + bias)                      (first conv, feeds the second)
 //   mode 1: out_f32  = mish(conv + bias) + resid_f32          (second conv + the "+ x" of InputEmbedding, dit.py:176)
@@ -23,7 +25,7 @@ struct ConvPosArgs {
   bf16* out_bf16; int ldo;
   float* out_f32; int ldo32;
   const float* resid; int ldr;
-  int S, N, D, mode, tiles_t;
+  int S, N, D, mode, tiles_t, cpg;
 };
 
 __device__ __forceinline__ void glds16c(const void* g, void* lds) {
@@ -43,8 +45,9 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int tt = bid % a.tiles_t; bid /= a.tiles_t;
-  const int G = a.D / 64;
+  const int G = a.D / a.cpg;
   const int g = bid % G;
+  const int c0 = g * a.cpg;  // first channel of this group
   const int seq = bid / G;
   const int t0 = tt * BT;
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
     const int row = i >> 3, c = i & 7;
     const int t = t0 - HALO + row;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (t >= 0 && t < a.N) v = *(const uint4*)(a.x + ((size_t)seq * a.N + t) * a.ldx + g * 64 + c * 8);
+    if (t >= 0 && t < a.N && c0 + c * 8 < a.D) v = *(const uint4*)(a.x + ((size_t)seq * a.N + t) * a.ldx + c0 + c * 8);
     *(uint4*)(Xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
   }
 
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
     const size_t m = (size_t)seq * a.N + t;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int n = g * 64 + wn0 + i * 16 + fq * 4;
+      const int oc = wn0 + i * 16 + fq * 4;
+      if (oc >= a.cpg) continue;
+      const int n = c0 + oc;
       f32x4 v = acc[i][j] + *(const f32x4*)(a.bias + n);
       v[0] = mish_f(v[0]); v[1] = mish_f(v[1]); v[2] = mish_f(v[2]); v[3] = mish_f(v[3]);
       if (a.mode == 0) {
@@ -179,9 +184,12 @@ inline int grid_for(size_t total) {
 extern "C" {
 
 int f5e_convpos(hipStream_t st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
-                void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D) {
+                void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
+                int groups) {
   F5E_REQUIRE(x && w_packed && bias, "convpos: null operand");
-  F5E_REQUIRE(S > 0 && N > 0 && D > 0 && D % 64 == 0, "convpos: D=%d must be a positive multiple of 64", D);
+  F5E_REQUIRE(S > 0 && N > 0 && D > 0 && groups > 0 && D % groups == 0, "convpos: bad D=%d / groups=%d", D, groups);
+  const int cpg = D / groups;
+  F5E_REQUIRE(cpg % 16 == 0 && cpg <= 64, "convpos: channels per group = %d must be 16, 32, 48 or 64", cpg);
   F5E_REQUIRE(ldx % 8 == 0, "convpos: ldx must be a multiple of 8");
   if (mode == 0) F5E_REQUIRE(out_bf16 && ldo % 4 == 0, "convpos: mode 0 needs a bf16 output");
   else {
@@ -191,9 +199,9 @@ int f5e_convpos(hipStream_t st, const void* x, int ldx, const void* w_packed, co
   ConvPosArgs a{};
   a.x = (const bf16*)x; a.ldx = ldx; a.w = (const bf16*)w_packed; a.bias = bias;
   a.out_bf16 = (bf16*)out_bf16; a.ldo = ldo; a.out_f32 = out_f32; a.ldo32 = ldo32; a.resid = resid; a.ldr = ldr;
-  a.S = S; a.N = N; a.D = D; a.mode = mode;
+  a.S = S; a.N = N; a.D = D; a.mode = mode; a.cpg = cpg;
   a.tiles_t = (N + 63) / 64;
-  const int grid = a.tiles_t * (D / 64) * S;
+  const int grid = a.tiles_t * groups * S;
   const int lds = ((94 * 128 + 255) & ~255) + 3 * 8192;
   hipLaunchKernelGGL(convpos_kernel, dim3(grid), dim3(256), lds, st, a);
   F5E_LAUNCH_CHECK("convpos");

@@ -34,6 +34,7 @@ struct GemmArgs {
   bf16* q; bf16* k; bf16* vt;
   int n_pad; int heads; int rope_heads;
   const float* cos_sin;  // [rows_per_seq][32][2]
+  const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
   int tiles_m, tiles_n;
 };
 
@@ -194,6 +195,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
       seq = m / a.rows_per_seq;
       pos = m - seq * a.rows_per_seq;
     }
+    // optional qk RMSNorm (reference modules.py:464-467 + :275-294): needs a whole head (64 columns) in one wave,
+    // i.e. the 128-wide tile; 16 values in-lane, the other 48 in the lanes fr + 16/32/48
+    float qk_rn = 1.0f;
+    const float* qk_w = nullptr;
+    if constexpr (EPI == EPI_QKV_ROPE && WN == 64) {
+      const int which_w = (n0 + wn0) / (a.heads * 64);
+      if (a.qn_w && which_w < 2) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          f32x4 t = acc[i][j];
+          if (a.bias) t += *(const f32x4*)(a.bias + n0 + wn0 + i * 16 + fq * 4);
+          ss += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        qk_rn = rsqrtf(ss * (1.0f / 64.0f) + a.qk_eps);
+        qk_w = which_w == 0 ? a.qn_w : a.kn_w;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int n = n0 + wn0 + i * 16 + fq * 4;
@@ -229,6 +250,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         const int which = n / inner;
         const int nn = n - which * inner;
         const int head = nn >> 6, d = nn & 63;
+        if (qk_w) v = v * qk_rn * *(const f32x4*)(qk_w + d);
         if (which < 2 && head < a.rope_heads) {
           const f32x4 cs = *(const f32x4*)(a.cos_sin + ((size_t)pos * 32 + (d >> 1)) * 2);
           const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
@@ -291,6 +313,7 @@ template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int sel = tile_hint % 10, ns = tile_hint / 10;
+  if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
     // tools/gemm_tune.py on MI355X has 64x64 / 3 stages fastest for every DiT shape at M = 938
@@ -363,12 +386,15 @@ int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const vo
 
 int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
                            void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
-                           int rows_per_seq, int M, int K, int tile_hint) {
+                           const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                           int tile_hint) {
   GemmArgs a{};
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = 3 * heads * 64; a.K = K;
   a.q = (bf16*)q; a.k = (bf16*)k; a.vt = (bf16*)vt; a.n_pad = n_pad; a.heads = heads; a.rope_heads = rope_heads;
   a.cos_sin = cos_sin; a.rows_per_seq = rows_per_seq;
+  a.qn_w = q_norm_w; a.kn_w = k_norm_w; a.qk_eps = 1e-6f;
+  F5E_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "gemm_bf16_qkv_rope: q and k norm weights go together");
   if (int e = check_common(a)) return e;
   F5E_REQUIRE(q && k && vt && cos_sin, "gemm_bf16_qkv_rope: null output/table");
   F5E_REQUIRE(heads > 0 && rope_heads >= 0 && rope_heads <= heads, "gemm_bf16_qkv_rope: bad head counts");

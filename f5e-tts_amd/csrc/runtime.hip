@@ -153,16 +153,21 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
   F5E_TIMED(F5E_OP_INPROJ, f5e_gemm_f32(st, p->y, p->mel, p->B * p->N, F5E_ACT_NONE, p->w_x, p->ldw_x, nullptr, F5E_ACT_NONE, nullptr,
                        p->in_const, D, M, nullptr, p->h0, D, p->h0_bf16, D, M, D, p->mel));
   // K5: conv position embedding + residual (dit.py:176)
-  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D));
-  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D));
+  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D, p->convpos_groups));
+  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D, p->convpos_groups));
 
+  if (p->w_skip) {  // long skip connection keeps the embedded input (backbones/dit.py:456-457)
+    F5E_REQUIRE(p->skip_res && p->skip_tmp, "dit_forward: long skip needs skip_res / skip_tmp");
+    HIP_TRY(hipMemcpyAsync(p->skip_res, p->x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st),
+            "hipMemcpyAsync(skip_res)");
+  }
   for (int l = 0; l < p->L; ++l) {
     const f5e_dit_block_weights& w = p->blocks[l];
     const float* mb = p->mod + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     F5E_TIMED(F5E_OP_LN, f5e_layernorm(st, p->x, D, p->hn, D, 1, nullptr, nullptr, mb + D, mb, row_stride, p->mod_rows, p->N,
                           p->eval_ptr, eval_stride, M, D, 1e-6f));
     F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope(st, p->hn, D, w.w_qkv, D, w.b_qkv, p->q, p->k, p->vt, p->n_pad, p->H, p->rope_heads,
-                                   p->rope_cs, p->N, M, D, 0));
+                                   p->rope_cs, w.q_norm_w, w.k_norm_w, p->N, M, D, 0));
     F5E_TIMED(F5E_OP_ATTN, f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
     F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D, row_stride,
                                         p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D, inner, 0));
@@ -171,6 +176,12 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias(st, p->hn, D, w.w_ff1, D, w.b_ff1, p->ff, p->FF, M, p->FF, D, F5E_ACT_GELU_TANH, 0, 0));
     F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D, row_stride,
                                         p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF, 0));
+  }
+  if (p->w_skip) {  // x = Linear_{2D->D, no bias}(cat(x, residual)) as two fp32 GEMMs (dit.py:466-467)
+    F5E_TRY(f5e_gemm_f32(st, p->x, D, M, F5E_ACT_NONE, p->w_skip, 2 * D, nullptr, F5E_ACT_NONE, nullptr, nullptr, 0, 0,
+                         nullptr, p->skip_tmp, D, nullptr, 0, M, D, D));
+    F5E_TRY(f5e_gemm_f32(st, p->skip_res, D, M, F5E_ACT_NONE, p->w_skip + D, 2 * D, nullptr, F5E_ACT_NONE, nullptr,
+                         p->skip_tmp, D, M, nullptr, p->x, D, nullptr, 0, M, D, D));
   }
   // K13: final AdaLN (scale, shift order: modules.py:333) + proj_out
   const float* mf = p->mod + (size_t)p->L * 6 * D;

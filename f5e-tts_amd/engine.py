@@ -49,13 +49,11 @@ class DiTConfig:
             raise _C.F5EError("HIP path is built for dim_head = 64")
         if self.dim % 256 or self.text_dim % 256:
             raise _C.F5EError(f"HIP path needs dim and text_dim to be multiples of 256 (got {self.dim}, {self.text_dim})")
-        if (self.dim // 16) != 64:
-            raise _C.F5EError("ConvPositionEmbedding kernel is built for 64 channels per group (dim = 1024 with "
-                              f"groups = 16); got dim = {self.dim}")
-        if self.qk_norm is not None:
-            raise _C.F5EError("qk_norm is not on the F5TTS_v1_Base path and is not built yet")
-        if self.long_skip_connection:
-            raise _C.F5EError("long_skip_connection is not on the F5TTS_v1_Base path and is not built yet")
+        if (self.dim // 16) % 16 or self.dim // 16 > 64:
+            raise _C.F5EError("ConvPositionEmbedding kernel needs dim/16 in {16, 32, 48, 64} channels per group; "
+                              f"got dim = {self.dim}")
+        if self.qk_norm not in (None, "rms_norm"):
+            raise _C.F5EError(f"unknown qk_norm {self.qk_norm!r}")
         if self.mel_dim % 4:
             raise _C.F5EError("mel_dim must be a multiple of 4")
 
@@ -129,13 +127,11 @@ class DiTEngine:
                 convs.append((wf, ((b - mu) * s + be).contiguous()))
             self.ppg = dict(w0=f(pp + "0.weight"), b0=f(pp + "0.bias"), convs=convs,
                             w15=f(pp + "15.weight"), b15=f(pp + "15.bias"))
-        # conv position embedding: [D][64][31] -> [G][tap][oc][ic] bf16
-        G = D // 64
+        # conv position embedding: [D][D/16][31] -> [16 groups][tap][64 oc][64 ic] bf16 (zero padded)
         self.cp = []
         for j in (0, 2):
             w = f(f"input_embed.conv_pos_embed.conv1d.{j}.weight")
-            self.cp.append((w.view(G, 64, 64, 31).permute(0, 3, 1, 2).contiguous().to(BF),
-                            f(f"input_embed.conv_pos_embed.conv1d.{j}.bias")))
+            self.cp.append((ops.pack_convpos_weight(w, 16), f(f"input_embed.conv_pos_embed.conv1d.{j}.bias")))
         inv = sd.get("rotary_embed.inv_freq")
         self.inv_freq = (inv.detach().float() if inv is not None
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
@@ -151,10 +147,15 @@ class DiTEngine:
             w_out, b_out = f(p + "attn.to_out.0.weight").to(BF), f(p + "attn.to_out.0.bias")
             w_ff1, b_ff1 = f(p + "ff.ff.0.0.weight").to(BF), f(p + "ff.ff.0.0.bias")
             w_ff2, b_ff2 = f(p + "ff.ff.2.weight").to(BF), f(p + "ff.ff.2.bias")
-            keep = (w_qkv, b_qkv, w_out, b_out, w_ff1, b_ff1, w_ff2, b_ff2)
+            keep = [w_qkv, b_qkv, w_out, b_out, w_ff1, b_ff1, w_ff2, b_ff2]
+            names = ["w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2"]
+            if cfg.qk_norm == "rms_norm":
+                keep += [f(p + "attn.q_norm.weight"), f(p + "attn.k_norm.weight")]
+                names += ["q_norm_w", "k_norm_w"]
             self.blocks_keep.append(keep)
-            for name, t in zip(("w_qkv", "b_qkv", "w_out", "b_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2"), keep):
+            for name, t in zip(names, keep):
                 setattr(self.block_arr[i], name, t.data_ptr())
+        self.skip_w = f("long_skip_connection.weight") if cfg.long_skip_connection else None
         self.final_w, self.final_b = f("norm_out.linear.weight"), f("norm_out.linear.bias")
         self.proj_w, self.proj_b = f("proj_out.weight").to(BF), f("proj_out.bias")
         self.row_stride = L * 6 * D + 2 * D
@@ -302,12 +303,16 @@ class DiTEngine:
         p.in_const = in_const.data_ptr()
         p.convpos_w1, p.convpos_b1 = self.cp[0][0].data_ptr(), self.cp[0][1].data_ptr()
         p.convpos_w2, p.convpos_b2 = self.cp[1][0].data_ptr(), self.cp[1][1].data_ptr()
+        p.convpos_groups = 16
         p.rope_cs = rope_cs.data_ptr()
         p.seq_len = seq_len.data_ptr() if seq_len is not None else None
         p.mod = mod.data_ptr()
         p.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
         p.blocks = self.block_arr
         p.w_proj, p.b_proj = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+        if self.skip_w is not None:
+            ws["skip_res"], ws["skip_tmp"] = torch.empty(M, D, device=dv), torch.empty(M, D, device=dv)
+            p.w_skip = self.skip_w.data_ptr()
         for k, t in ws.items():
             setattr(p, k, t.data_ptr())
         return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len))

@@ -197,8 +197,8 @@ class DiTBlock(nn.Module):
     @torch.no_grad()
     def forward(self, x, t, mask=None, rope=None):
         """x [b, n, d], t [b, d] time embedding, mask bool [b, n] or None, rope = (freqs [1, n, 64], scale)."""
-        if self.dim_head != 64 or self.attn.q_norm is not None:
-            raise _C.F5EError("DiTBlock HIP path: dim_head must be 64 and qk_norm None")
+        if self.dim_head != 64:
+            raise _C.F5EError("DiTBlock HIP path: dim_head must be 64")
         ops.require_device()
         B, N, D = x.shape
         dv = x.device
@@ -223,7 +223,9 @@ class DiTBlock(nn.Module):
                 ops.rope_table(freqs[0, 1, 0::2].to(F32).contiguous(), cs)  # angle at position 1 = inv_freq
             else:
                 cs[..., 0] = 1.0
-        ops.gemm_bf16_qkv_rope(hn, w["w_qkv"], w["b_qkv"], q, k, vt, H, rope_heads, cs, N)
+        qn = self.attn.q_norm.weight.detach().to(dv, F32).contiguous() if self.attn.q_norm is not None else None
+        kn = self.attn.k_norm.weight.detach().to(dv, F32).contiguous() if self.attn.k_norm is not None else None
+        ops.gemm_bf16_qkv_rope(hn, w["w_qkv"], w["b_qkv"], q, k, vt, H, rope_heads, cs, N, q_norm_w=qn, k_norm_w=kn)
         lens = mask.sum(-1).to(I32).contiguous() if mask is not None else None
         if mask is not None and not torch.equal(mask, torch.arange(N, device=dv)[None] < lens[:, None]):
             raise _C.F5EError("attention kernel takes key-padding masks of the lens_to_mask form only")

@@ -71,14 +71,16 @@ def gemm_bf16_gate_residual(a: Tensor, w: Tensor, bias: Optional[Tensor], resid:
 
 
 def gemm_bf16_qkv_rope(a: Tensor, w: Tensor, bias: Tensor, q: Tensor, k: Tensor, vt: Tensor, heads: int,
-                       rope_heads: int, cos_sin: Tensor, rows_per_seq: int, tile_hint: int = 0):
+                       rope_heads: int, cos_sin: Tensor, rows_per_seq: int, tile_hint: int = 0,
+                       q_norm_w: Optional[Tensor] = None, k_norm_w: Optional[Tensor] = None):
     require_device()
     M, K = a.shape
     n_pad = q.shape[2]
     check(lib().f5e_gemm_bf16_qkv_rope(
         _stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0), _p(bias, F32, "bias"), _p(q, BF, "q"),
-        _p(k, BF, "k"), _p(vt, BF, "vt"), n_pad, heads, rope_heads, _p(cos_sin, F32, "cos_sin"), rows_per_seq, M, K,
-        tile_hint), "f5e_gemm_bf16_qkv_rope")
+        _p(k, BF, "k"), _p(vt, BF, "vt"), n_pad, heads, rope_heads, _p(cos_sin, F32, "cos_sin"),
+        _p(q_norm_w, F32, "q_norm_w"), _p(k_norm_w, F32, "k_norm_w"), rows_per_seq, M, K, tile_hint),
+        "f5e_gemm_bf16_qkv_rope")
 
 
 def qk_frag_index(n_pad: int) -> Tensor:
@@ -161,6 +163,14 @@ def gemm_f32(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out: Option
     return out if out is not None else out_bf16
 
 
+def pack_convpos_weight(w: Tensor, groups: int = 16) -> Tensor:
+    """Conv1d weight [D][D/groups][31] -> bf16 [groups][31][64 oc][64 ic] (zero padded to 64 x 64 per group)."""
+    D, cpg, taps = w.shape
+    out = torch.zeros(groups, taps, 64, 64, dtype=w.dtype, device=w.device)
+    out[:, :, :cpg, :cpg] = w.view(groups, cpg, cpg, taps).permute(0, 3, 1, 2)
+    return out.to(BF).contiguous()
+
+
 def convpos(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_bf16: Optional[Tensor] = None,
             out_f32: Optional[Tensor] = None, resid: Optional[Tensor] = None):
     require_device()
@@ -169,7 +179,8 @@ def convpos(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_bf
     check(lib().f5e_convpos(_stream(), _p(x, BF, "x"), x.stride(0), _p(w_packed, BF, "w_packed"), _p(bias, F32, "bias"),
                             mode, _p(out_bf16, BF, "out_bf16"), out_bf16.stride(0) if out_bf16 is not None else 0,
                             _p(out_f32, F32, "out_f32"), out_f32.stride(0) if out_f32 is not None else 0,
-                            _p(resid, F32, "resid"), resid.stride(0) if resid is not None else 0, S, N, D),
+                            _p(resid, F32, "resid"), resid.stride(0) if resid is not None else 0, S, N, D,
+                            w_packed.shape[0]),
           "f5e_convpos")
 
 

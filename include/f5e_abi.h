@@ -60,10 +60,12 @@ int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, const voi
  * (rows: q | k | v).  Outputs: q, k [S][heads][n_pad][64] bf16, vt [S][heads][64][n_pad] bf16 (V transposed).
  * cos_sin: [rows_per_seq][32][2] f32 from f5e_rope_table.  Pad rows/columns of q/k/vt are never written: the
  * caller zero-fills them once.
- * Replaces: modules.py:452-461 (projections + head split) and :470-480 (apply_rotary_pos_emb). */
+ * q_norm_w / k_norm_w: optional f32[64] RMSNorm weights applied per head before RoPE (qk_norm = "rms_norm", eps 1e-6).
+ * Replaces: modules.py:452-461 (projections + head split), :464-467 (qk norm) and :470-480 (apply_rotary_pos_emb). */
 int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
                            void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
-                           int rows_per_seq, int M, int K, int tile_hint);
+                           const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                           int tile_hint);
 
 /* ---------------------------------------------------------------- attention ---------------------------------- */
 
@@ -100,11 +102,12 @@ int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int a_act, 
 
 /* ---------------------------------------------------------------- convolutions ------------------------------- */
 
-/* One grouped Conv1d(D, D, 31, groups = D/64, padding = 15) + Mish of ConvPositionEmbedding (modules.py:167-190,
- * called with mask=None at backbones/dit.py:176).  x bf16 [S*N][ldx]; w_packed bf16 [D/64][31][64 oc][64 ic].
- * mode 0: out_bf16 = mish(conv + bias); mode 1: out_f32 = mish(conv + bias) + resid. */
+/* One grouped Conv1d(D, D, 31, groups, padding = 15) + Mish of ConvPositionEmbedding (modules.py:167-190, called with
+ * mask=None at backbones/dit.py:176).  x bf16 [S*N][ldx]; w_packed bf16 [groups][31][64 oc][64 ic], zero padded when
+ * D/groups (16, 32, 48 or 64) is below 64.  mode 0: out_bf16 = mish(conv + bias); mode 1: out_f32 = mish(..) + resid. */
 int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
-                void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D);
+                void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
+                int groups);
 
 /* Depthwise Conv1d(C, C, 7, padding 3, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [7][C]. */
 int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
@@ -151,6 +154,7 @@ typedef struct f5e_dit_block_weights {
   const void* w_out;  const float* b_out;  /* bf16 [D][H*64] */
   const void* w_ff1;  const float* b_ff1;  /* bf16 [FF][D] */
   const void* w_ff2;  const float* b_ff2;  /* bf16 [D][FF] */
+  const float* q_norm_w; const float* k_norm_w; /* f32 [64] each, or NULL (qk_norm off) */
 } f5e_dit_block_weights;
 
 typedef struct f5e_dit_plan {
@@ -162,12 +166,15 @@ typedef struct f5e_dit_plan {
   const float* in_const;      /* [S*N][D] f32: cond/text/ppg part of the input projection + bias, per branch */
   const void* convpos_w1; const float* convpos_b1;
   const void* convpos_w2; const float* convpos_b2;
+  int convpos_groups;         /* ConvPositionEmbedding groups (16 in the reference) */
   const float* rope_cs;       /* [N][32][2] */
   const int* seq_len;         /* [S] valid frames per sequence, or NULL (= N, the reference's mask=None case) */
   const float* mod;           /* [E][mod_rows][L*6*D + 2*D] f32 */
   const int* eval_ptr;        /* device int: current evaluation index into mod */
   const f5e_dit_block_weights* blocks; /* HOST array [L] */
   const void* w_proj; const float* b_proj; /* bf16 [mel][D], f32 [mel] */
+  const float* w_skip;        /* long_skip_connection.weight f32 [D][2D] or NULL (backbones/dit.py:264,466-467) */
+  float* skip_res; float* skip_tmp; /* [S*N][D] f32 each, only with w_skip */
   /* workspace (caller-owned, sizes in elements) */
   float* h0; void* h0_bf16; void* c1;   /* [S*N][D] f32 / bf16 / bf16 */
   float* x;                              /* [S*N][D] f32 residual stream */

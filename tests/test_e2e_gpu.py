@@ -21,7 +21,8 @@ def build(cfg: O.DiTConfig, seed=1234):
     ppg_config = dict(use_ppg=cfg.use_ppg, ppg_dim=cfg.ppg_dim, use_transformer=False)
     dit = DiT(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=64, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
               text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, text_mask_padding=cfg.text_mask_padding,
-              conv_layers=cfg.conv_layers, pe_attn_head=cfg.pe_attn_head, ppg_config=ppg_config)
+              conv_layers=cfg.conv_layers, pe_attn_head=cfg.pe_attn_head, qk_norm=cfg.qk_norm,
+              long_skip_connection=cfg.long_skip_connection, ppg_config=ppg_config)
     dit.load_state_dict(sd, strict=True)
     cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
     return sd, dit, cfm
@@ -155,3 +156,23 @@ def test_three_branch_samplers_with_ppg():
     o, t = cfm.sample(cond.cuda(), text.cuda(), ppg.cuda(), cfg_strength=2.0, **kw)
     ro, rt = O.cfm_sample(sd, cfg, cond, text, ppg, cfg_strength=2.0, **kw)
     assert rel_l2(t[-1], rt[-1]) < 2e-2, rel_l2(t[-1], rt[-1])
+
+
+def test_small_ppg_config_c5_shape():
+    """BASELINE config 5 architecture (reference configs/example.yaml: dim 768 -> 48 channels per conv-pos group,
+    12 heads, pe_attn_head 1, no text mask padding, PPG input) at reduced depth; plus qk_norm and long skip."""
+    for extra in (dict(), dict(qk_norm="rms_norm", long_skip_connection=True)):
+        cfg = O.DiTConfig(dim=768, depth=3, heads=12, ff_mult=2, text_dim=512, conv_layers=2, text_num_embeds=300,
+                          text_mask_padding=False, pe_attn_head=1, use_ppg=True, ppg_dim=256, **extra)
+        sd, dit, cfm = build(cfg)
+        g = torch.Generator().manual_seed(10)
+        cond = torch.randn(2, 33, 100, generator=g)
+        text = torch.randint(0, 300, (2, 10), generator=g)
+        ppg = torch.randn(2, 50, 256, generator=g)
+        kw = dict(duration=torch.tensor([80, 71]), lens=torch.tensor([33, 30]), steps=3, sway_sampling_coef=-1.0, seed=5)
+        o, t = cfm.sample(cond.cuda(), text.cuda(), ppg.cuda(), cfg_strength=2.0, **kw)
+        ro, rt = O.cfm_sample(sd, cfg, cond, text, ppg, cfg_strength=2.0, **kw)
+        assert rel_l2(t[-1], rt[-1]) < 2e-2, (extra, rel_l2(t[-1], rt[-1]))
+        o, t = cfm.sample_tts(cond.cuda(), text.cuda(), alpha_spk=2.5, alpha_txt=3.0, **kw)
+        ro, rt = O.cfm_sample(sd, cfg, cond, text, None, mode="tts", alpha_a=2.5, alpha_b=3.0, **kw)
+        assert rel_l2(t[-1], rt[-1]) < 2e-2, (extra, rel_l2(t[-1], rt[-1]))

@@ -227,15 +227,16 @@ def test_gemm_f32(ops, M, N, K):
         close(out, fn(ref), 1e-5, 3e-5, f"act {act}")
 
 
-@pytest.mark.parametrize("S,N,D", [(2, 469, 1024), (3, 70, 128), (1, 5, 64)])
-def test_convpos(ops, S, N, D):
-    G = D // 64
+@pytest.mark.parametrize("S,N,D,G", [(2, 469, 1024, 16), (3, 70, 128, 2), (1, 5, 64, 1), (2, 100, 768, 16),
+                                     (1, 130, 256, 16), (2, 65, 512, 16)])
+def test_convpos(ops, S, N, D, G):
+    cpg = D // G
     x = torch.randn(S, N, D, generator=g(31)).to(BF)
-    w = (torch.randn(D, 64, 31, generator=g(32)) / math.sqrt(64 * 31)).to(BF)
+    w = (torch.randn(D, cpg, 31, generator=g(32)) / math.sqrt(cpg * 31)).to(BF)
     b = torch.randn(D, generator=g(33)) * 0.1
     res = torch.randn(S * N, D, generator=g(34))
     conv = F.conv1d(x.float().permute(0, 2, 1), w.float(), b, padding=15, groups=G).permute(0, 2, 1).reshape(S * N, D)
-    wp = w.view(G, 64, 64, 31).permute(0, 3, 1, 2).contiguous()  # [G][tap][oc][ic]
+    wp = ops.pack_convpos_weight(w.float(), G)  # [G][tap][64 oc][64 ic], zero padded
     o16 = torch.empty(S * N, D, device="cuda", dtype=BF)
     ops.convpos(dev(x.view(S * N, D)), dev(wp), dev(b), S, N, out_bf16=o16)
     close(o16, F.mish(conv), 2 ** -7, 2e-3, "mode 0")
@@ -334,3 +335,27 @@ def test_istft_head(ops, B, T):
     out = torch.empty(B, 256 * (T - 1), device="cuda")
     ops.istft_head(dev(z), dev(win), dev(tw), torch.empty(B * T, 1024, device="cuda"), out, B, T, 1024, 256)
     close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "istft")
+
+
+def test_qkv_rope_with_qk_rmsnorm(ops):
+    """qk_norm = 'rms_norm' (reference modules.py:464-467): RMSNorm over the 64-d head before RoPE, q and k only."""
+    S, N, H, K = 2, 150, 12, 768
+    inner, n_pad = H * 64, 192
+    a = torch.randn(S * N, K, generator=g(50)).to(BF)
+    w = (torch.randn(3 * inner, K, generator=g(51)) / math.sqrt(K)).to(BF)
+    b = torch.randn(3 * inner, generator=g(52))
+    qw, kw = 1 + 0.2 * torch.randn(64, generator=g(53)), 1 + 0.2 * torch.randn(64, generator=g(54))
+    lin = (a.float() @ w.float().T + b).view(S, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    freqs = O.rope_freqs(N, 64)
+    q_ref = O.apply_rope(O.rms_norm(lin[0], qw), freqs)
+    k_ref = O.apply_rope(O.rms_norm(lin[1], kw), freqs)
+    cs = torch.empty(N, 32, 2, device="cuda")
+    ops.rope_table(dev(1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))), cs)
+    q = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
+    k, vt = torch.zeros_like(q), torch.zeros_like(q)
+    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, H, cs, N, q_norm_w=dev(qw), k_norm_w=dev(kw))
+    qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)
+    unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
+    close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q normed")
+    close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k normed")
+    close(unq(vt, vi)[:, :, :N], lin[2], 2 ** -7, 4e-3, "v untouched")
