@@ -146,8 +146,19 @@ def main():
         dom = max(per_op, key=lambda k: per_op[k][0] * per_op[k][1])
         avg_ms = per_op[dom][0]
         ach = gemm_flops(dom, M) / (avg_ms * 1e-3) / 1e12
+        # HBM traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+        # corrected per the microarch guide (tools/pmc_traffic.py); the committed summary is read back here
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload.lower()}.json")
+        if os.path.exists(tpath):
+            import re
+            epi = {"QKV": 3, "OUT": 2, "FF1": 1, "FF2": 2}[dom]
+            cands = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath))["kernels"].items()
+                     if re.match(rf"gemm_bf16_kernel<\d+, \d+, {epi},", k)]
+            if cands:
+                traffic = max(cands)[1]
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "kernel": {"QKV": "gemm_bf16_kernel<*,*,EPI_QKV_ROPE>", "OUT": "gemm_bf16_kernel<*,*,EPI_GATE_RES>",
                                "FF1": "gemm_bf16_kernel<*,*,EPI_BF16_GELU>", "FF2": "gemm_bf16_kernel<*,*,EPI_GATE_RES>"}[dom],
                     "op": dom, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": per_op[dom][1],

@@ -45,7 +45,15 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
   const int ql = lane & 31, hh = lane >> 5;
 
   const int qtiles = (a.rows_per_seq + 31) / 32;
+  // XCD-aware order: blocks with equal blockIdx%8 share an XCD (and its L2); give each XCD a contiguous range of
+  // logical ids so all q-tiles of one (sequence, head) -- which re-read the same K/V -- hit the same L2.
   int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
   const int qt = bid % qtiles;
   bid /= qtiles;
   const int head = bid % a.H;

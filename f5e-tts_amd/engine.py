@@ -432,11 +432,11 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     y = inp.y0.detach().clone().contiguous()
     y_mid = torch.empty_like(y) if eps_per_step == 2 else None
 
-    # Chains: at small batch a step is bound by the latency of ~160 dependent launches, not by MFMA or HBM, so the
-    # CFG branches (independent until the combine) run as PARALLEL chains of the captured graph and their fixed
-    # per-kernel costs overlap; weights are then read once per branch instead of once per step (L2/MALL absorb most
-    # of it at these sizes).  At larger batch the branches stay batched in one forward so weights stream once.
-    n_chains = nb if (chains is None and nb > 1 and S * N <= 4096) else (chains or 1)
+    # Chains (opt-in): the CFG branches are independent until the combine, so they can run as PARALLEL chains of the
+    # captured graph.  Measured on MI355X at C2 (tools/chain_ab.py): 57-70 ms/pass with high run-to-run variance vs
+    # a stable 60.5 ms for the single batched forward, so the default keeps ONE forward over all branches (weights
+    # stream once per step); results are bit-identical either way.
+    n_chains = chains or 1
     if nb % n_chains:
         raise _C.F5EError(f"chains={n_chains} must divide the number of CFG branches {nb}")
     per = nb // n_chains  # branches per chain
