@@ -388,7 +388,7 @@ def sway_time_grid(steps: int, sway: Optional[float], t_start: float = 0.0, dtyp
 
 def sample_prep(cond: Tensor, text: Optional[Tensor], duration, lens: Optional[Tensor], seed: Optional[int],
                 max_duration: int = 4096, no_ref_audio: bool = False, edit_mask: Optional[Tensor] = None,
-                num_channels: int = 100):
+                num_channels: int = 100, duplicate_test: bool = False, t_inter: float = 0.1):
     """cfm.py:378-428,452-457: masks, padding, duration clamp, seeded noise (CPU generator)."""
     b, nc = cond.shape[:2]
     if lens is None:
@@ -404,6 +404,7 @@ def sample_prep(cond: Tensor, text: Optional[Tensor], duration, lens: Optional[T
         duration = torch.maximum(lens + 1, duration)
     duration = duration.clamp(max=max_duration)
     n = int(duration.amax())
+    test_cond = F.pad(cond, (0, 0, nc, n - 2 * nc), value=0.0) if duplicate_test else None  # cfm.py:411-412
     cond = F.pad(cond, (0, 0, 0, n - nc), value=0.0)
     if no_ref_audio:
         cond = torch.zeros_like(cond)
@@ -415,14 +416,20 @@ def sample_prep(cond: Tensor, text: Optional[Tensor], duration, lens: Optional[T
         if seed is not None:
             torch.manual_seed(seed)
         y0[i, :dur] = torch.randn(dur, num_channels, dtype=step_cond.dtype)
-    return dict(cond=cond, cond_mask=cond_mask, step_cond=step_cond, mask=mask, y0=y0, duration=duration, n=n)
+    t_start = 0.0
+    if duplicate_test:  # cfm.py:462-465
+        t_start = t_inter
+        y0 = (1 - t_start) * y0 + t_start * test_cond
+    return dict(cond=cond, cond_mask=cond_mask, step_cond=step_cond, mask=mask, y0=y0, duration=duration, n=n,
+                t_start=t_start)
 
 
 def cfm_sample(sd: State, cfg: DiTConfig, cond: Tensor, text: Optional[Tensor], ppg: Optional[Tensor] = None,
                duration=None, *, lens: Optional[Tensor] = None, steps: int = 32, cfg_strength: float = 1.0,
                sway_sampling_coef: Optional[float] = None, seed: Optional[int] = None, max_duration: int = 4096,
                no_ref_audio: bool = False, edit_mask: Optional[Tensor] = None, method: str = "euler",
-               mode: str = "cfg", alpha_a: float = 1.0, alpha_b: float = 1.0) -> Tuple[Tensor, Tensor]:
+               mode: str = "cfg", alpha_a: float = 1.0, alpha_b: float = 1.0, duplicate_test: bool = False,
+               t_inter: float = 0.1) -> Tuple[Tensor, Tensor]:
     """CFM.sample (mode='cfg', cfm.py:349-482), sample_tts (mode='tts', :94-223), sample_vc (mode='vc', :226-346).
 
     ``cond`` is a mel [B, Nc, 100] or a raw wave [B, nw].  Returns (out, trajectory).
@@ -432,7 +439,9 @@ def cfm_sample(sd: State, cfg: DiTConfig, cond: Tensor, text: Optional[Tensor], 
         cond = log_mel_spectrogram(cond).permute(0, 2, 1)
     cond = cond.float()
     prep = sample_prep(cond, text if mode != "vc" else None, duration, lens, seed, max_duration, no_ref_audio,
-                       edit_mask, cond.shape[-1])
+                       edit_mask, cond.shape[-1], duplicate_test, t_inter)
+    if duplicate_test:
+        steps = int(steps * (1 - prep["t_start"]))
     step_cond, mask = prep["step_cond"], prep["mask"]
     cache: dict = {}
 
@@ -462,7 +471,7 @@ def cfm_sample(sd: State, cfg: DiTConfig, cond: Tensor, text: Optional[Tensor], 
     else:
         raise ValueError(mode)
 
-    t = sway_time_grid(steps, sway_sampling_coef)
+    t = sway_time_grid(steps, sway_sampling_coef, prep["t_start"])
     traj = odeint_fixed(fn, prep["y0"], t, method)
     out = torch.where(prep["cond_mask"], prep["cond"], traj[-1])
     return out, traj

@@ -176,3 +176,42 @@ def test_small_ppg_config_c5_shape():
         o, t = cfm.sample_tts(cond.cuda(), text.cuda(), alpha_spk=2.5, alpha_txt=3.0, **kw)
         ro, rt = O.cfm_sample(sd, cfg, cond, text, None, mode="tts", alpha_a=2.5, alpha_b=3.0, **kw)
         assert rel_l2(t[-1], rt[-1]) < 2e-2, (extra, rel_l2(t[-1], rt[-1]))
+
+
+def test_sampler_flags_and_edges():
+    """CFM.sample keyword paths: lens shorter than the cond, text longer than the duration (truncation + duration
+    bump), max_duration clamp, no_ref_audio, edit_mask, duplicate_test, and a ragged batch of three."""
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    g = torch.Generator().manual_seed(11)
+    cond = torch.randn(3, 50, 100, generator=g)
+    text = torch.randint(0, 300, (3, 70), generator=g)
+    text[1, 20:] = -1
+    text[2, 5:] = -1
+    base = dict(duration=torch.tensor([60, 90, 120]), lens=torch.tensor([50, 41, 33]), steps=3, cfg_strength=2.0,
+                sway_sampling_coef=-1.0, seed=6)
+    edit = torch.ones(3, 50, dtype=torch.bool)
+    edit[:, 10:20] = False
+    for extra in (dict(), dict(max_duration=100), dict(no_ref_audio=True), dict(edit_mask=edit),
+                  dict(duplicate_test=True, t_inter=0.25, steps=8), dict(sway_sampling_coef=None)):
+        kw = dict(base, **extra)
+        o, t = cfm.sample(cond.cuda(), text.cuda(), **{k: (v.cuda() if isinstance(v, torch.Tensor) else v)
+                                                       for k, v in kw.items()})
+        ro, rt = O.cfm_sample(sd, cfg, cond, text, None, **kw)
+        assert o.shape == ro.shape and t.shape == rt.shape, (extra, o.shape, ro.shape)
+        assert torch.equal(t[0].cpu(), rt[0]) or extra.get("duplicate_test"), extra
+        assert rel_l2(t[-1], rt[-1]) < 1.5e-2, (extra, rel_l2(t[-1], rt[-1]))
+        assert rel_l2(o, ro) < 1.5e-2, extra
+
+
+def test_max_duration_4096_single_forward():
+    """Longest supported sequence (max_duration = 4096 frames, reference cfm.py:361): one DiT evaluation, 2 blocks."""
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, _ = build(cfg)
+    g = torch.Generator().manual_seed(12)
+    N = 4096
+    x, cond = torch.randn(1, N, 100, generator=g), torch.randn(1, N, 100, generator=g)
+    text = torch.randint(0, 300, (1, 500), generator=g)
+    ref = O.dit_sample(sd, cfg, x, cond, text, None, torch.tensor(0.5), False, False, False, None)
+    out = dit.sample(x.cuda(), cond.cuda(), text.cuda(), None, torch.tensor(0.5).cuda(), False, False, False, None)
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
