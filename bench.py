@@ -69,11 +69,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torch.distributed.run: always RCCL
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        # RCCL writes its banner / warnings to stdout: send them to a file so stdout carries exactly one JSON line
+        os.environ["NCCL_DEBUG"] = os.environ.get("F5E_NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/f5e_rccl_%h_%p.log")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))  # RCCL on ROCm
 
     from f5e_tts_amd import ops
     from f5e_tts_amd._C import OP_FF1, OP_FF2, OP_OUT, OP_QKV

@@ -212,6 +212,153 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// ---- LDS-shared variant for large problems ------------------------------------------------------------------------
+// Same math and register layout as attn_fwd_kernel, but a workgroup = 4 waves = 128 queries of one (sequence, head) and
+// every 64-key K/V tile is fetched ONCE per workgroup into LDS (3-stage LDS-DMA ring, counted vmcnt + raw barrier,
+// as in gemm_bf16.hip) instead of once per wave from L2: 4x less L2->CU traffic, which is what bounds the LDS-free
+// kernel once S*H*N^2 is large (C3: 7.4 GB of L2 reads per call).  The fragment-major K / V tiles are contiguous in
+// memory (K: 2 x 4 KiB, V: 2 x 4 KiB per 64 keys), so the DMA is a linear copy and a fragment read is
+// ds_read_b128 at fragment*1 KiB + (lane&31)*32 + (lane>>5)*16 (2-way bank conflict, LDS is far from saturated).
+__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
+  constexpr int TILE_BYTES = 16384;  // K 8 KiB + V 8 KiB per 64 keys
+  constexpr int NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hh = lane >> 5;
+
+  const int qblocks = (a.rows_per_seq + 127) / 128;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int qb = bid % qblocks;
+  bid /= qblocks;
+  const int head = bid % a.H;
+  const int seq = bid / a.H;
+  const size_t sh = (size_t)seq * a.H + head;
+  const int kv_len = a.kv_len ? min(a.kv_len[seq], a.rows_per_seq) : a.rows_per_seq;
+  const int ntiles = (kv_len + 63) / 64;
+
+  const bf16* Qg = a.q + sh * a.n_pad * 64;
+  const char* Kg = (const char*)(a.k + sh * a.n_pad * 64);
+  const char* Vg = (const char*)(a.v + sh * a.n_pad * 64);
+
+  const int qt = min(qb * 4 + wave, a.n_pad / 32 - 1);  // this wave's 32-query tile (clamped: pad rows are zero)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + ((size_t)(qt * 4 + ks) * 32 + ql) * 16 + hh * 8);
+
+  // stage t64: K bytes [t64*8192, +8192) and V bytes [t64*8192, +8192); 1024 chunks of 16 B, 4 per thread
+  auto stage = [&](int buf, int t64) {
+    char* dst = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = (wave * 64 + 256 * j) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + (size_t)t64 * 8192 + off + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (size_t)t64 * 8192 + off + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + 8192 + off), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (ntiles > 0) stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  int buf = 0, nbuf = 2;
+  for (int t64 = 0; t64 < ntiles; ++t64) {
+    if (t64 + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t64 + 2 < ntiles) stage(nbuf, t64 + 2);
+    const char* Ks = smem + buf * TILE_BYTES;
+    const char* Vs = Ks + 8192;
+
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16);
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
+      }
+    }
+    const int key_base = t64 * 64 + 4 * hh;
+    const bool partial = (t64 * 64 + 64 > kv_len);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sc = st[t][r] * a.scale_log2e;
+        if (partial) {
+          const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= kv_len) sc = -INFINITY;
+        }
+        st[t][r] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(st[t][r] - m_new);
+        st[t][r] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[t][8 * s + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          // V fragment (tile t, s16 = s, dt): index ((t*2 + s)*2 + dt), each 1 KiB, lane-linear
+          const bf16x8 vf = *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + ql * 32 + hh * 16);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    buf = (buf == NST - 1) ? 0 : buf + 1;
+    nbuf = (nbuf == NST - 1) ? 0 : nbuf + 1;
+  }
+
+  const int q_row = (qb * 4 + wave) * 32 + ql;
+  if (q_row < a.rows_per_seq) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16* op = a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *(bf16x4*)(op + dt * 32 + 8 * g) = f2bf4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv,
+                                                   oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, const void* v, void* o, int ldo,
@@ -226,6 +373,14 @@ extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, cons
   a.kv_len = kv_len; a.S = S; a.H = H; a.rows_per_seq = rows_per_seq; a.n_pad = n_pad;
   a.scale_log2e = 0.125f * 1.4426950408889634f;
   const int grid = ((rows_per_seq + 31) / 32) * H * S;
+  // Large problems: K/V shared through LDS by 128-query workgroups (splits = -1 forces it, 0 picks it when the
+  // LDS-free kernel would already have >= 8 waves per CU without any KV split)
+  if (splits == -1 || (splits == 0 && grid >= 8192)) {
+    const int g128 = ((rows_per_seq + 127) / 128) * H * S;
+    hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(g128), dim3(256), 3 * 16384, st, a);
+    F5E_LAUNCH_CHECK("flash_attn_lds");
+    return F5E_OK;
+  }
   if (splits <= 0) {
     // aim for >= ~2k waves (2 per SIMD on 256 CUs) without splitting sequences that have few key tiles
     const int ktiles = (rows_per_seq + 63) / 64;
@@ -236,7 +391,7 @@ extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, cons
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid), dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid), dim3(128), 0, st, a); break;
     case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a); break;
-    default: F5E_REQUIRE(false, "flash_attn: splits must be 0 (auto), 1, 2 or 4");
+    default: F5E_REQUIRE(false, "flash_attn: splits must be 0 (auto), -1 (LDS-shared), 1, 2 or 4");
   }
   F5E_LAUNCH_CHECK("flash_attn");
   return F5E_OK;

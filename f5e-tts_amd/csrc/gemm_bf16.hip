@@ -51,13 +51,14 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
+  constexpr int NT = 64 * WGM * WGN;  // threads: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + W_BYTES;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -79,20 +80,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 
   // ---- staging: chunk i (16 B) of a [rows][64] bf16 tile sits at LDS byte i*16 ----
   // source chunk for LDS position (row, c) is c ^ ((row>>1)&7)
-  constexpr int A_IT = BM * 8 / 256;
-  constexpr int W_IT = BN * 8 / 256;
+  constexpr int A_IT = BM * 8 / NT;
+  constexpr int W_IT = BN * 8 / NT;
+  static_assert(A_IT >= 1 && W_IT >= 1 && A_IT * NT == BM * 8 && W_IT * NT == BN * 8, "tile / thread-count mismatch");
   const bf16* a_src[A_IT];
   const bf16* w_src[W_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, a.M - 1);
     a_src[j] = a.A + (size_t)gr * a.lda + c * 8;
   }
 #pragma unroll
   for (int j = 0; j < W_IT; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
     const int gr = min(n0 + row, a.N - 1);
     w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
@@ -100,12 +102,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + 256 * j) * 16);
+    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + 256 * j) * 16);
+    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
   };
 
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int fr = lane & 15, fq = lane >> 4;
 
   f32x4 acc[TN][TM];
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -289,11 +291,11 @@ int launch(GemmArgs& a, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
   if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, 0, WGM, WGN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, 0, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -324,7 +326,14 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   // stages: 128x128 wants 2 (64 KiB LDS -> 2 workgroups per CU; measured 386 vs 556 us at M = 60k), small tiles 3
   if (ns == 0) ns = (sel == 1) ? 2 : 3;
   switch (sel * 10 + ns) {
-    case 12: return launch<128, 128, EPI, 2>(a, st);
+    // 128x128: 8 waves (4 x 2, 32 x 64 per wave), 2 workgroups per CU = 16 waves per CU to cover the per-K-step
+    // waits; measured at M = 60k (rocprofv3): QKV 564 vs 710 us, gated residual 324 vs 381, FF1 363 vs 377 for the
+    // 4-wave 2 x 2 grid.  (256-wide tiles and 3 stages were slower.)
+    case 12: return launch<128, 128, EPI, 2, 4, 2>(a, st);
+    case 42: return launch<128, 128, EPI, 2, 2, 2>(a, st);   // 4 waves, 64 x 64 per wave (tuning reference)
+    case 53: return launch<256, 128, EPI, 3, 4, 2>(a, st);   // experiments: bigger tiles, 1 workgroup per CU
+    case 62: return launch<256, 256, EPI, 2, 4, 2>(a, st);
+    case 72: return launch<256, 256, EPI, 2, 2, 4>(a, st);
     case 13: return launch<128, 128, EPI, 3>(a, st);
     case 22: return launch<128, 64, EPI, 2>(a, st);
     case 23: return launch<128, 64, EPI, 3>(a, st);

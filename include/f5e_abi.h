@@ -71,7 +71,7 @@ int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W,
 
 /* o[S*rows_per_seq][ldo] (bf16, column = head*64 + d) = softmax(q k^T / 8 + keymask) v, keys >= kv_len[s] masked.
  * q, k, v use the fragment-major layouts documented in csrc/attention.hip; splits: KV splits per 32-query tile
- * (0 = auto, 1, 2 or 4).
+ * (0 = auto, 1, 2 or 4; -1 = the LDS-shared 128-query kernel that auto picks for large problems).
  * Replaces: F.scaled_dot_product_attention + transpose/reshape (modules.py:482-492). */
 int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, void* o, int ldo, const int* kv_len,
                    int S, int H, int rows_per_seq, int n_pad, int splits);

@@ -136,7 +136,9 @@ def pack_qkv(ops, q, k, v, n_pad):
 
 
 @pytest.mark.parametrize("S,H,N,waves,masked", [(2, 16, 469, 0, False), (2, 4, 469, 4, True), (3, 2, 64, 2, True),
-                                                (1, 2, 130, 4, False), (2, 2, 33, 1, True), (1, 16, 1875, 0, False)])
+                                                (1, 2, 130, 4, False), (2, 2, 33, 1, True), (1, 16, 1875, 0, False),
+                                                (2, 4, 469, -1, True), (1, 2, 130, -1, False), (3, 2, 64, -1, True),
+                                                (2, 2, 33, -1, True), (8, 16, 938, 0, True)])
 def test_flash_attn(ops, S, H, N, waves, masked):
     n_pad = (N + 63) // 64 * 64
     q = torch.randn(S, H, N, 64, generator=g(12)).to(BF)
