@@ -35,7 +35,7 @@ struct GemmArgs {
   int n_pad; int heads; int rope_heads;
   const float* cos_sin;  // [rows_per_seq][32][2]
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, m_major;
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
@@ -74,8 +74,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int tile_n = bid / a.tiles_m;
-  const int tile_m = bid - tile_n * a.tiles_m;
+  // consecutive logical ids (= one XCD's L2) share the LARGER operand's panel: the weight panel when N*K >= M*K
+  // (small batch), the activation panel when M > N (large batch: otherwise A is re-fetched once per n-panel)
+  int tile_m, tile_n;
+  if (a.m_major) {
+    tile_m = bid / a.tiles_n;
+    tile_n = bid - tile_m * a.tiles_n;
+  } else {
+    tile_n = bid / a.tiles_m;
+    tile_m = bid - tile_n * a.tiles_m;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- staging: chunk i (16 B) of a [rows][64] bf16 tile sits at LDS byte i*16 ----
@@ -287,6 +295,7 @@ template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
+  a.m_major = a.M > a.N;
   const int grid = a.tiles_m * a.tiles_n;
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
@@ -304,6 +313,7 @@ template <int EPI, int DBG>
 int launch_dbg(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 63) / 64;
   a.tiles_n = (a.N + 63) / 64;
+  a.m_major = 0;
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, EPI, 3, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), 3 * 128 * 128, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_dbg");
   return F5E_OK;
