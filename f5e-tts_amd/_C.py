@@ -33,6 +33,7 @@ SIGNATURES = {
     "f5e_advance_eval": [_P, _P],
     "f5e_stitch": [_P, _P, _P, _P, _P, _LL, _I],
     "f5e_cast_bf16": [_P, _P, _P, _LL],
+    "f5e_vq_eval": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_dit_forward": [_P, _P],

@@ -100,6 +100,80 @@ __global__ void cast_bf16_kernel(const float* x, bf16* y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (bf16)x[i];
 }
 
+// GumbelVectorQuantizer.forward in eval mode (reference model/modules.py:881-950): per (row, group) argmax of the
+// logits -> one-hot -> codebook row; targets = the argmax indices.  One wave per (row, group).
+__global__ __launch_bounds__(256) void vq_lookup_kernel(const float* logits, int ld, const float* vars, int combine,
+                                                         float* out, int* targets, int rows, int G, int V, int vd) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long long)rows * G) return;
+  const int r = (int)(item / G), g = (int)(item % G);
+  const float* lp = logits + (size_t)r * ld + (size_t)g * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) {
+    const float x = lp[v];
+    if (x > best) { best = x; bi = v; }  // strict: the smallest index wins within a lane
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }  // first maximal index, as torch.max
+  }
+  if (lane == 0 && targets) targets[(size_t)r * G + g] = bi;
+  const float* src = vars + ((size_t)(combine ? 0 : g) * V + bi) * vd;
+  for (int d = lane; d < vd; d += 64) out[(size_t)r * G * vd + (size_t)g * vd + d] = src[d];
+}
+
+// code / prob perplexity of the same forward: hard_probs = mean one-hot, avg_probs = mean softmax, each
+// exp(-sum p log(p + 1e-7)) summed over groups.  One block, deterministic (no atomics).
+__global__ __launch_bounds__(256) void vq_stats_kernel(const float* logits, int ld, const int* targets, float* stats,
+                                                        int rows, int G, int V) {
+  extern __shared__ float sm[];  // [4 waves][V] softmax sums, then [V] counts
+  float* accw = sm;
+  float* cnt = sm + 4 * V;
+  __shared__ float red[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float code_ppl = 0.f, prob_ppl = 0.f;
+  for (int g = 0; g < G; ++g) {
+    for (int i = tid; i < 5 * V; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    for (int r = wave; r < rows; r += 4) {
+      const float* lp = logits + (size_t)r * ld + (size_t)g * V;
+      float mx = -INFINITY;
+      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lp[v]);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int v = lane; v < V; v += 64) s += expf(lp[v] - mx);
+      s = wave_sum(s);
+      const float inv = 1.0f / s;
+      for (int v = lane; v < V; v += 64) accw[wave * V + v] += expf(lp[v] - mx) * inv;
+    }
+    __syncthreads();
+    if (tid == 0)  // counts: serial over rows keeps it exact and ordered (rows is a few thousand at most)
+      for (int r = 0; r < rows; ++r) cnt[targets[(size_t)r * G + g]] += 1.0f;
+    __syncthreads();
+    float hc = 0.f, hp = 0.f;
+    for (int v = tid; v < V; v += 256) {
+      const float p_hard = cnt[v] / (float)rows;
+      const float p_avg = ((accw[v] + accw[V + v]) + (accw[2 * V + v] + accw[3 * V + v])) / (float)rows;
+      hc += p_hard * logf(p_hard + 1e-7f);
+      hp += p_avg * logf(p_avg + 1e-7f);
+    }
+    hc = wave_sum(hc);
+    hp = wave_sum(hp);
+    if (tid == 0) { red[0] = 0.f; red[1] = 0.f; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&red[0], hc); atomicAdd(&red[1], hp); }  // 4 LDS adds per group
+    __syncthreads();
+    code_ppl += expf(-red[0]);
+    prob_ppl += expf(-red[1]);
+    __syncthreads();
+  }
+  if (tid == 0) { stats[0] = code_ppl; stats[1] = prob_ppl; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -154,6 +228,23 @@ int f5e_stitch(hipStream_t st, const float* cond, const float* y, const unsigned
   hipLaunchKernelGGL(stitch_kernel, dim3(grid_for((size_t)rows * C)), dim3(256), 0, st, cond, y, mask, out,
                      (size_t)rows, C);
   F5E_LAUNCH_CHECK("stitch");
+  return F5E_OK;
+}
+
+int f5e_vq_eval(hipStream_t st, const float* logits, int ld, const float* vars, int combine_groups, float* out,
+                int* targets, float* stats, int rows, int groups, int num_vars, int var_dim) {
+  F5E_REQUIRE(logits && vars && out && targets, "vq_eval: null operand");
+  F5E_REQUIRE(rows > 0 && groups > 0 && num_vars > 0 && var_dim > 0 && ld >= groups * num_vars, "vq_eval: bad shape");
+  const long long items = (long long)rows * groups;
+  hipLaunchKernelGGL(vq_lookup_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, logits, ld, vars,
+                     combine_groups, out, targets, rows, groups, num_vars, var_dim);
+  F5E_LAUNCH_CHECK("vq_lookup");
+  if (stats) {
+    F5E_REQUIRE(num_vars <= 2048, "vq_eval: statistics kernel supports num_vars <= 2048");
+    hipLaunchKernelGGL(vq_stats_kernel, dim3(1), dim3(256), 5 * num_vars * sizeof(float), st, logits, ld, targets, stats,
+                       rows, groups, num_vars);
+    F5E_LAUNCH_CHECK("vq_stats");
+  }
   return F5E_OK;
 }
 

@@ -237,3 +237,74 @@ class DiTBlock(nn.Module):
         ops.gemm_bf16_bias(hn, w["w_ff1"], w["b_ff1"], ff, act=ops.ACT_GELU_TANH)
         ops.gemm_bf16_gate_residual(ff, w["w_ff2"], w["b_ff2"], xs, emb[:, 5 * D:6 * D], N)
         return xs.view(B, N, D)
+
+
+# ---------------------------------------------------------------- codebook (reference modules.py:744-950, eval only)
+
+class GumbelVectorQuantizer(nn.Module):
+    """Constructor / state_dict mirror of the reference quantizer; ``forward`` is the EVAL branch only (per-group
+    argmax -> codebook row) on libf5e_hip.so.  The reference never calls it from ``DiT.sample``: this is
+    the parity-only op BASELINE config 5 names."""
+
+    def __init__(self, dim, num_vars, temp, groups, combine_groups, vq_dim, time_first, activation=nn.GELU(),
+                 weight_proj_depth=1, weight_proj_factor=1, hard=True, std=0):
+        super().__init__()
+        self.groups, self.combine_groups, self.input_dim, self.num_vars = groups, combine_groups, dim, num_vars
+        self.time_first, self.hard = time_first, hard
+        assert vq_dim % groups == 0, f"dim {vq_dim} must be divisible by groups {groups} for concatenation"
+        var_dim = vq_dim // groups
+        num_groups = groups if not combine_groups else 1
+        self.vars = nn.Parameter(torch.empty(1, num_groups * num_vars, var_dim))
+        nn.init.uniform_(self.vars) if std == 0 else nn.init.normal_(self.vars, mean=0, std=std)
+        if weight_proj_depth > 1:
+            if not isinstance(activation, nn.GELU):
+                raise _C.F5EError("weight_proj activation other than GELU is not built")
+            inner = self.input_dim * weight_proj_factor
+            blocks = [nn.Sequential(nn.Linear(self.input_dim if i == 0 else inner, inner), activation)
+                      for i in range(weight_proj_depth - 1)]
+            self.weight_proj = nn.Sequential(*blocks, nn.Linear(inner, groups * num_vars))
+        else:
+            self.weight_proj = nn.Linear(self.input_dim, groups * num_vars)
+            nn.init.normal_(self.weight_proj.weight, mean=0, std=1)
+            nn.init.zeros_(self.weight_proj.bias)
+        if isinstance(temp, str):
+            import ast
+            temp = ast.literal_eval(temp)
+        assert len(temp) == 3, f"{temp}, {len(temp)}"
+        self.max_temp, self.min_temp, self.temp_decay = temp
+        self.curr_temp = self.max_temp
+
+    def set_num_updates(self, num_updates):
+        self.curr_temp = max(self.max_temp * self.temp_decay ** num_updates, self.min_temp)
+
+    @torch.no_grad()
+    def forward(self, x, produce_targets=False):
+        if self.training:
+            raise NotImplementedError("gumbel-softmax training branch is out of scope (SURVEY section 8)")
+        ops.require_device()
+        result = {"num_vars": self.num_vars * self.groups}
+        if not self.time_first:
+            x = x.transpose(1, 2)
+        bsz, tsz, fsz = x.shape
+        dv = x.device
+        h = x.reshape(-1, fsz).to(F32).contiguous()
+        layers = [self.weight_proj] if isinstance(self.weight_proj, nn.Linear) else list(self.weight_proj)
+        for layer in layers:
+            lin, act = (layer, ops.ACT_NONE) if isinstance(layer, nn.Linear) else (layer[0], ops.ACT_GELU_ERF)
+            o = torch.empty(h.shape[0], lin.out_features, device=dv)
+            ops.gemm_f32(h, lin.weight.detach().to(dv, F32).contiguous(), lin.bias.detach().to(dv, F32).contiguous(),
+                         out=o, act=act)
+            h = o
+        vd = self.vars.shape[-1]
+        out = torch.empty(bsz * tsz, self.groups * vd, device=dv)
+        targets = torch.empty(bsz * tsz, self.groups, device=dv, dtype=I32)
+        stats = torch.empty(2, device=dv)
+        ops.vq_eval(h, self.vars.detach().to(dv, F32)[0].contiguous(), self.combine_groups, out, targets, stats,
+                    self.groups, self.num_vars)
+        result["code_perplexity"], result["prob_perplexity"] = stats[0], stats[1]
+        result["temp"] = self.curr_temp
+        if produce_targets:
+            result["targets"] = targets.view(bsz, tsz, self.groups).long()
+        xq = out.view(bsz, tsz, -1)
+        result["x"] = xq if self.time_first else xq.transpose(1, 2)
+        return result

@@ -254,6 +254,16 @@ def cast_bf16(x: Tensor, out: Tensor):
     return out
 
 
+def vq_eval(logits: Tensor, vars_: Tensor, combine_groups: bool, out: Tensor, targets: Tensor,
+            stats: Optional[Tensor], groups: int, num_vars: int):
+    require_device()
+    rows = logits.shape[0]
+    check(lib().f5e_vq_eval(_stream(), _p(logits, F32, "logits"), logits.stride(0), _p(vars_, F32, "vars"),
+                            1 if combine_groups else 0, _p(out, F32, "out"), _p(targets, I32, "targets"),
+                            _p(stats, F32, "stats"), rows, groups, num_vars, vars_.shape[-1]), "f5e_vq_eval")
+    return out
+
+
 def stft_logmel(wav: Tensor, window: Tensor, twiddle: Tensor, fb: Tensor, out: Tensor, n_fft: int, hop: int):
     require_device()
     B, nw = wav.shape

@@ -135,6 +135,11 @@ int f5e_advance_eval(f5e_stream st, int* eval_ptr);
 int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
                int C);
 int f5e_cast_bf16(f5e_stream st, const float* x, void* y, long long n);
+/* GumbelVectorQuantizer eval forward (model/modules.py:881-950): logits f32 [rows][ld] (groups * num_vars used) ->
+ * targets i32 [rows][groups] (first maximal index), out f32 [rows][groups * var_dim] gathered from vars f32
+ * [(combine_groups ? 1 : groups) * num_vars][var_dim]; stats (optional) f32[2] = (code_perplexity, prob_perplexity). */
+int f5e_vq_eval(f5e_stream st, const float* logits, int ld, const float* vars, int combine_groups, float* out,
+                int* targets, float* stats, int rows, int groups, int num_vars, int var_dim);
 
 /* ---------------------------------------------------------------- mel / vocoder ------------------------------ */
 

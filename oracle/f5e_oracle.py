@@ -521,18 +521,30 @@ def vocos_decode(vs: State, mel: Tensor) -> Tensor:
 # K18 GumbelVectorQuantizer eval forward (parity-only; modules.py:881-950)
 # --------------------------------------------------------------------------
 
-def gumbel_vq_eval(x: Tensor, w: Tensor, b: Tensor, codebook: Tensor, groups: int, num_vars: int) -> Tensor:
-    """Eval branch: logits = Linear(x); per-group argmax -> one-hot -> sum_v onehot*vars, concat groups.
+def gumbel_vq_eval(x: Tensor, layers, codebook: Tensor, groups: int, num_vars: int,
+                   combine_groups: bool = False) -> Dict[str, Tensor]:
+    """GumbelVectorQuantizer.forward, eval branch (modules.py:881-950), time_first input [B, T, C].
 
-    ``codebook``: vars [1, groups*num_vars, vq_dim/groups] (combine_groups=False).
+    ``layers``: [(weight, bias, gelu_after)] of weight_proj; ``codebook``: vars [1, (1 or groups)*num_vars, var_dim].
+    Returns x, targets, code_perplexity, prob_perplexity.
     """
-    bsz, tsz, _ = x.shape
-    logits = F.linear(x.reshape(-1, x.shape[-1]), w, b).view(bsz * tsz * groups, num_vars)
-    k = logits.argmax(dim=-1)
-    cb = codebook.squeeze(0).view(groups, num_vars, -1)
-    k = k.view(bsz * tsz, groups)
-    out = torch.cat([cb[g, k[:, g]] for g in range(groups)], dim=-1)
-    return out.view(bsz, tsz, -1)
+    bsz, tsz, fsz = x.shape
+    h = x.reshape(-1, fsz)
+    for w, b, gelu in layers:
+        h = F.linear(h, w, b)
+        if gelu:
+            h = F.gelu(h)
+    logits = h.view(bsz * tsz * groups, num_vars)
+    k = logits.max(-1)[1]
+    hard = torch.zeros_like(logits).scatter_(-1, k.view(-1, 1), 1.0).view(bsz * tsz, groups, num_vars)
+    hard_probs = hard.float().mean(dim=0)
+    code_ppl = torch.exp(-torch.sum(hard_probs * torch.log(hard_probs + 1e-7), dim=-1)).sum()
+    avg_probs = torch.softmax(logits.view(bsz * tsz, groups, num_vars).float(), dim=-1).mean(dim=0)
+    prob_ppl = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-7), dim=-1)).sum()
+    vars_ = codebook.repeat(1, groups, 1) if combine_groups else codebook
+    q = (hard.view(bsz * tsz, -1).unsqueeze(-1) * vars_).view(bsz * tsz, groups, num_vars, -1).sum(-2)
+    return dict(x=q.view(bsz, tsz, -1), targets=k.view(bsz, tsz, groups), code_perplexity=code_ppl,
+                prob_perplexity=prob_ppl)
 
 
 # --------------------------------------------------------------------------

@@ -421,11 +421,38 @@ def make_callers_case(ref_root, cfm_mod):
     print("wrote", path)
 
 
+def make_vq_case(modules_mod):
+    """Eval forward of the reference GumbelVectorQuantizer (three constructor variants)."""
+    out = {}
+    for tag, kw in (("plain", dict(groups=2, combine_groups=False, weight_proj_depth=1)),
+                    ("combine", dict(groups=2, combine_groups=True, weight_proj_depth=1)),
+                    ("deep", dict(groups=4, combine_groups=False, weight_proj_depth=2, weight_proj_factor=2))):
+        torch.manual_seed(77)
+        m = modules_mod.GumbelVectorQuantizer(dim=32, num_vars=10, temp=(2, 0.5, 0.999995), vq_dim=32, time_first=True,
+                                              **kw).eval()
+        x = torch.randn(2, 13, 32)
+        with torch.no_grad():
+            r = m(x, produce_targets=True)
+        out[f"{tag}/x"] = x
+        out[f"{tag}/q"] = r["x"]
+        out[f"{tag}/targets"] = r["targets"]
+        out[f"{tag}/code_perplexity"] = r["code_perplexity"]
+        out[f"{tag}/prob_perplexity"] = r["prob_perplexity"]
+        for k, v in m.state_dict().items():
+            out[f"{tag}/w/{k}"] = v
+    path = os.path.join(HERE, "vq_eval.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path)
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     modules_mod, dit_mod, cfm_mod, utils_mod = load_reference(ref)
     if len(sys.argv) > 2 and sys.argv[2] == "callers":
         make_callers_case(ref, cfm_mod)
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "vq":
+        make_vq_case(modules_mod)
         return
     small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
                  conv_layers=2)
@@ -440,6 +467,7 @@ def main():
                   n_ppg=21, mode="vc")
     make_prep_case(cfm_mod, dit_mod)
     make_callers_case(ref, cfm_mod)
+    make_vq_case(modules_mod)
 
 
 if __name__ == "__main__":

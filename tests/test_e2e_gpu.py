@@ -215,3 +215,24 @@ def test_max_duration_4096_single_forward():
     ref = O.dit_sample(sd, cfg, x, cond, text, None, torch.tensor(0.5), False, False, False, None)
     out = dit.sample(x.cuda(), cond.cuda(), text.cuda(), None, torch.tensor(0.5).cuda(), False, False, False, None)
     assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("tag,groups,combine,depth", [("plain", 2, False, 1), ("combine", 2, True, 1), ("deep", 4, False, 2)])
+def test_gumbel_vq_eval_against_reference_fixture(tag, groups, combine, depth):
+    """The HIP codebook lookup against vectors produced by the reference's own GumbelVectorQuantizer (eval mode)."""
+    import os
+
+    import numpy as np
+
+    from f5e_tts_amd.model.modules import GumbelVectorQuantizer
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vq_eval.npz"))
+    g = {k[len(tag) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/")}
+    m = GumbelVectorQuantizer(dim=32, num_vars=10, temp=(2, 0.5, 0.999995), groups=groups, combine_groups=combine,
+                              vq_dim=32, time_first=True, weight_proj_depth=depth, weight_proj_factor=2)
+    m.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("w/")}, strict=True)
+    m = m.cuda().eval()
+    r = m(g["x"].cuda(), produce_targets=True)
+    assert torch.equal(r["targets"].cpu(), g["targets"])          # integer work: bit exact
+    assert torch.equal(r["x"].cpu(), g["q"])                       # pure gather: bit exact
+    torch.testing.assert_close(r["code_perplexity"].cpu(), g["code_perplexity"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r["prob_perplexity"].cpu(), g["prob_perplexity"], rtol=1e-5, atol=1e-5)

@@ -108,13 +108,25 @@ def test_mel_and_istft_third_party_crosschecks():
     assert torch.isfinite(wav).all()
 
 
-def test_gumbel_vq_eval_shapes():
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 5, 16, generator=g)
-    w = torch.randn(2 * 10, 16, generator=g)
-    b = torch.zeros(20)
-    cb = torch.randn(1, 20, 8, generator=g)
-    q = O.gumbel_vq_eval(x, w, b, cb, groups=2, num_vars=10)
-    assert q.shape == (2, 5, 16)
-    k0 = (x[0, 0] @ w[:10].T).argmax()
-    torch.testing.assert_close(q[0, 0, :8], cb[0, k0])
+def _vq_case(tag):
+    z = np.load(os.path.join(GOLD, "vq_eval.npz"))
+    g = {k[len(tag) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/")}
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w/")}
+    if "weight_proj.weight" in w:
+        layers = [(w["weight_proj.weight"], w["weight_proj.bias"], False)]
+    else:
+        n = max(int(k.split(".")[1]) for k in w if k.startswith("weight_proj."))
+        layers = [(w[f"weight_proj.{i}.0.weight"], w[f"weight_proj.{i}.0.bias"], True) for i in range(n)]
+        layers.append((w[f"weight_proj.{n}.weight"], w[f"weight_proj.{n}.bias"], False))
+    groups = {"plain": 2, "combine": 2, "deep": 4}[tag]
+    return g, w, layers, groups
+
+
+@pytest.mark.parametrize("tag", ["plain", "combine", "deep"])
+def test_gumbel_vq_eval_matches_reference(tag):
+    g, w, layers, groups = _vq_case(tag)
+    r = O.gumbel_vq_eval(g["x"], layers, w["vars"], groups, 10, combine_groups=(tag == "combine"))
+    assert torch.equal(r["targets"], g["targets"])
+    torch.testing.assert_close(r["x"], g["q"], rtol=0, atol=0)
+    torch.testing.assert_close(r["code_perplexity"], g["code_perplexity"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(r["prob_perplexity"], g["prob_perplexity"], rtol=1e-6, atol=1e-6)
