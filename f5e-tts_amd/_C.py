@@ -22,6 +22,7 @@ SIGNATURES = {
     "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
     "f5e_grn": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "f5e_l2norm": [_P, _P, _I, _P, _I, _I, _P, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],

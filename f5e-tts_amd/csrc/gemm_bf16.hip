@@ -341,7 +341,9 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     // 4-wave 2 x 2 grid.  (256-wide tiles and 3 stages were slower.)
     case 12: return launch<128, 128, EPI, 2, 4, 2>(a, st);
     case 42: return launch<128, 128, EPI, 2, 2, 2>(a, st);   // 4 waves, 64 x 64 per wave (tuning reference)
-    case 53: return launch<256, 128, EPI, 3, 4, 2>(a, st);   // experiments: bigger tiles, 1 workgroup per CU
+    case 83: return launch<128, 128, EPI, 3, 4, 2>(a, st);   // experiments: deeper rings / bigger tiles, 1 workgroup per CU
+    case 84: return launch<128, 128, EPI, 4, 4, 2>(a, st);
+    case 53: return launch<256, 128, EPI, 3, 4, 2>(a, st);
     case 62: return launch<256, 256, EPI, 2, 4, 2>(a, st);
     case 72: return launch<256, 256, EPI, 2, 2, 4>(a, st);
     case 13: return launch<128, 128, EPI, 3>(a, st);

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
 }
 
+// x_transformers.RMSNorm as UNetT uses it (reference backbones/unett.py:151,161,178): F.normalize(x, dim=-1) * sqrt(D) * g
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, int ldx, void* y, int ldy, int y_bf16,
+                                                      const float* g, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xp = x + (size_t)row * ldx;
+  f32x4 v[VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *(const f32x4*)(xp + (i * 64 + lane) * 4);
+    ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  }
+  const float scale = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const f32x4 o = v[i] * scale * *(const f32x4*)(g + c);
+    if (y_bf16) *(bf16x4*)((bf16*)y + (size_t)row * ldy + c) = f2bf4(o[0], o[1], o[2], o[3]);
+    else *(f32x4*)((float*)y + (size_t)row * ldy + c) = o;
+  }
+}
+
 // GRN pass 1: gx[b][c] = sqrt(sum_t x[b][t][c]^2)   x: [B][T][C] fp32
 __global__ __launch_bounds__(256) void grn_norm_kernel(const float* x, float* gx, int T, int C) {
   __shared__ float red[4][64];
@@ -132,6 +157,25 @@ int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int
     default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, a); break;
   }
   F5E_LAUNCH_CHECK("layernorm");
+  return F5E_OK;
+}
+
+int f5e_l2norm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D) {
+  F5E_REQUIRE(x && y && g && rows > 0, "l2norm: null/empty");
+  F5E_REQUIRE(D % 256 == 0 && D >= 256 && D <= 2048, "l2norm: D=%d must be a multiple of 256 in [256, 2048]", D);
+  F5E_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "l2norm: ldx/ldy must be multiples of 4");
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL(l2norm_kernel<1>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 2: hipLaunchKernelGGL(l2norm_kernel<2>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 3: hipLaunchKernelGGL(l2norm_kernel<3>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 4: hipLaunchKernelGGL(l2norm_kernel<4>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 5: hipLaunchKernelGGL(l2norm_kernel<5>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 6: hipLaunchKernelGGL(l2norm_kernel<6>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    case 7: hipLaunchKernelGGL(l2norm_kernel<7>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+    default: hipLaunchKernelGGL(l2norm_kernel<8>, grid, block, 0, st, x, ldx, y, ldy, y_bf16, g, rows, D); break;
+  }
+  F5E_LAUNCH_CHECK("l2norm");
   return F5E_OK;
 }
 

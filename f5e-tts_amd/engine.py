@@ -86,7 +86,8 @@ def text_pos_table(dim: int, end: int = 4096, theta: float = 10000.0) -> Tensor:
 class DiTEngine:
     """Device-resident, repacked weights of one DiT + the code that runs it through the C ABI."""
 
-    def __init__(self, sd: Dict[str, Tensor], cfg: DiTConfig, device):
+    def __init__(self, sd: Dict[str, Tensor], cfg: DiTConfig, device, blocks: bool = True):
+        """blocks=False loads only the front-end shared with UNetT (time MLP, text embedding, input embedding)."""
         cfg.validate()
         ops.require_device()
         self.cfg = cfg
@@ -135,6 +136,11 @@ class DiTEngine:
         inv = sd.get("rotary_embed.inv_freq")
         self.inv_freq = (inv.detach().float() if inv is not None
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
+        self._graphs: Dict[tuple, "_LoopGraph"] = {}
+        self._tables: Dict[tuple, Tensor] = {}
+        self._lock = threading.Lock()
+        if not blocks:
+            return
         # --- per-block weights: AdaLN linears stay fp32 (tables), the four block linears go bf16
         self.adaln = []
         self.blocks_keep = []
@@ -160,9 +166,6 @@ class DiTEngine:
         self.proj_w, self.proj_b = f("proj_out.weight").to(BF), f("proj_out.bias")
         self.row_stride = L * 6 * D + 2 * D
         self.rope_heads = cfg.heads if cfg.pe_attn_head is None else cfg.pe_attn_head
-        self._graphs: Dict[tuple, "_LoopGraph"] = {}
-        self._tables: Dict[tuple, Tensor] = {}
-        self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ once-per-call pieces
 
@@ -180,18 +183,24 @@ class DiTEngine:
                 self._tables[key] = hit
         return hit
 
+    def time_embed(self, flat_t: Tensor) -> Tensor:
+        """TimestepEmbedding (modules.py:721-731): f32 [n] -> f32 [n, dim]."""
+        cfg, dv = self.cfg, self.device
+        n = flat_t.shape[0]
+        sin = torch.empty(n, 256, device=dv)
+        ops.sinus_embed(flat_t.contiguous(), self.sinus_freqs, sin)
+        h = torch.empty(n, cfg.dim, device=dv)
+        ops.gemm_f32(sin, self.tm_w0, self.tm_b0, out=h, act=ops.ACT_SILU)
+        temb = torch.empty(n, cfg.dim, device=dv)
+        ops.gemm_f32(h, self.tm_w2, self.tm_b2, out=temb)
+        return temb
+
     def time_tables(self, t: Tensor) -> Tensor:
         """t: f32 [E] (or [E, rows]) -> modulation table [E, rows, L*6D + 2D] f32 (K2 + the AdaLN linears)."""
         cfg, dv = self.cfg, self.device
         t2 = t.reshape(t.shape[0], -1)
         E, rows = t2.shape
-        flat = t2.reshape(-1).contiguous()
-        sin = torch.empty(E * rows, 256, device=dv)
-        ops.sinus_embed(flat, self.sinus_freqs, sin)
-        h = torch.empty(E * rows, cfg.dim, device=dv)
-        ops.gemm_f32(sin, self.tm_w0, self.tm_b0, out=h, act=ops.ACT_SILU)
-        temb = torch.empty(E * rows, cfg.dim, device=dv)
-        ops.gemm_f32(h, self.tm_w2, self.tm_b2, out=temb)
+        temb = self.time_embed(t2.reshape(-1))
         mod = torch.empty(E * rows, self.row_stride, device=dv)
         D = cfg.dim
         for l, (w, b) in enumerate(self.adaln):

@@ -130,6 +130,15 @@ def layernorm(x: Tensor, out: Tensor, gamma: Optional[Tensor] = None, beta: Opti
     return out
 
 
+def l2norm(x: Tensor, out: Tensor, g: Tensor):
+    """out = x / ||x|| * sqrt(D) * g (x_transformers.RMSNorm); x f32 [rows, D], out bf16 or f32."""
+    require_device()
+    rows, D = x.shape
+    check(lib().f5e_l2norm(_stream(), _p(x, F32, "x"), x.stride(0), _p(out, None, "out"), out.stride(0),
+                           1 if out.dtype == BF else 0, _p(g, F32, "g"), rows, D), "f5e_l2norm")
+    return out
+
+
 def grn(x: Tensor, out: Tensor, gamma: Tensor, beta: Tensor, ws: Tensor):
     require_device()
     B, T, Cc = x.shape

@@ -86,6 +86,9 @@ int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int 
                   const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
                   int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps);
 
+/* x_transformers.RMSNorm used by UNetT (backbones/unett.py:151,161,178): y = x / max(||x||_2, 1e-12) * sqrt(D) * g. */
+int f5e_l2norm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D);
+
 /* GRN over the sequence axis (modules.py:225-234): x, y f32 [B][T][C]; gx_ws f32 [B][C] scratch. */
 int f5e_grn(f5e_stream st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B, int T,
             int C);

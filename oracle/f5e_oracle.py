@@ -353,6 +353,54 @@ def dit_sample(sd: State, cfg: DiTConfig, x: Tensor, cond: Tensor, text: Optiona
 
 
 # --------------------------------------------------------------------------
+# UNetT.forward                           (backbones/unett.py:184-250; f4 row)
+# --------------------------------------------------------------------------
+
+def x_rmsnorm(x: Tensor, g: Tensor) -> Tensor:
+    """x_transformers.RMSNorm (UNPINNED third party): F.normalize(x, dim=-1) * sqrt(dim) * g."""
+    return F.normalize(x, dim=-1) * (x.shape[-1] ** 0.5) * g
+
+
+def unett_forward(sd: State, heads: int, x: Tensor, cond: Tensor, text: Tensor, time: Tensor, drop_audio_cond: bool,
+                  drop_text: bool, mask: Optional[Tensor] = None, skip_connect_type: str = "concat",
+                  text_mask_padding: bool = True, pe_attn_head: Optional[int] = None) -> Tensor:
+    b, n = x.shape[0], x.shape[1]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = time_embedding(sd, time)
+    text_emb = text_embedding(sd, text, b, n, drop_text, mask_padding=text_mask_padding)
+    h = input_embedding(sd, x, cond, text_emb, None, drop_audio_cond)
+    h = torch.cat([t.unsqueeze(1), h], dim=1)                       # time token in front (unett.py:215)
+    if mask is not None:
+        mask = F.pad(mask, (1, 0), value=True)
+    dh = sd["layers.0.2.to_q.weight"].shape[0] // heads
+    freqs = rope_freqs(n + 1, dh, sd.get("rotary_embed.inv_freq"))
+    depth = 0
+    while f"layers.{depth}.2.to_q.weight" in sd:
+        depth += 1
+    skips = []
+    for idx in range(depth):
+        layer = idx + 1
+        p = f"layers.{idx}."
+        if layer <= depth // 2:
+            skips.append(h)
+        else:
+            skip = skips.pop()
+            if skip_connect_type == "concat":
+                h = F.linear(torch.cat((h, skip), dim=-1), sd[p + "0.weight"])
+            elif skip_connect_type == "add":
+                h = h + skip
+        h = attention(sd, p + "2.", x_rmsnorm(h, sd[p + "1.g"]), heads, mask, freqs, pe_attn_head) + h
+        f = x_rmsnorm(h, sd[p + "3.g"])
+        f = F.linear(f, sd[p + "4.ff.0.0.weight"], sd[p + "4.ff.0.0.bias"])
+        f = F.gelu(f, approximate="tanh")
+        f = F.linear(f, sd[p + "4.ff.2.weight"], sd[p + "4.ff.2.bias"])
+        h = f + h
+    h = x_rmsnorm(h, sd["norm_out.g"])[:, 1:, :]
+    return F.linear(h, sd["proj_out.weight"], sd["proj_out.bias"])
+
+
+# --------------------------------------------------------------------------
 # a19 fixed-grid ODE solvers              (torchdiffeq, UNPINNED; App C2)
 # --------------------------------------------------------------------------
 

@@ -421,6 +421,35 @@ def make_callers_case(ref_root, cfm_mod):
     print("wrote", path)
 
 
+def make_unett_case():
+    """Reference UNetT.forward (backbones/unett.py) on two small seeded configs."""
+    unett_mod = importlib.import_module("f5_tts.model.backbones.unett")
+    for tag, skip, b in (("concat_b1", "concat", 1), ("add_b2", "add", 2)):
+        torch.manual_seed(900)
+        m = unett_mod.UNetT(dim=128, depth=4, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50,
+                            text_dim=32, conv_layers=2, skip_connect_type=skip).eval()
+        g = torch.Generator().manual_seed(901)
+        for name, p in m.named_parameters():
+            if name.endswith(".g") or "grn" in name:
+                p.data.add_(0.1 * torch.randn(p.shape, generator=g))
+        n = 40
+        x, cond = torch.randn(b, n, 20, generator=g), torch.randn(b, n, 20, generator=g)
+        text = torch.randint(0, 50, (b, 9), generator=g)
+        mask = None
+        if b > 1:
+            text[1, 6:] = -1
+            mask = torch.arange(n)[None] < torch.tensor([n, n - 6])[:, None]
+        out = {"x": x, "cond": cond, "text": text, "mask": mask, "time": torch.tensor(0.41)}
+        with torch.no_grad():
+            for drop in (False, True):
+                out["pred_drop%d" % int(drop)] = m(x, cond, text, torch.tensor(0.41), drop_audio_cond=drop,
+                                                   drop_text=drop, mask=mask)
+        out.update({"w/" + k: v for k, v in m.state_dict().items()})
+        path = os.path.join(HERE, f"unett_{tag}.npz")
+        np.savez_compressed(path, **_np(out))
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_vq_case(modules_mod):
     """Eval forward of the reference GumbelVectorQuantizer (three constructor variants)."""
     out = {}
@@ -454,6 +483,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "vq":
         make_vq_case(modules_mod)
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "unett":
+        make_unett_case()
+        return
     small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
                  conv_layers=2)
     make_dit_case(dit_mod, cfm_mod, "b1", small, b=1, n=48, nc=17, nt=9, steps=4, cfg_strength=2.0, seed=100)
@@ -468,6 +500,7 @@ def main():
     make_prep_case(cfm_mod, dit_mod)
     make_callers_case(ref, cfm_mod)
     make_vq_case(modules_mod)
+    make_unett_case()
 
 
 if __name__ == "__main__":

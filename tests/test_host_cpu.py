@@ -97,6 +97,17 @@ def test_state_dict_layout_matches_reference(tag):
     m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}, strict=True)
 
 
+def test_unett_state_dict_layout_matches_reference():
+    from f5e_tts_amd.model import UNetT
+    for tag, skip in (("concat_b1", "concat"), ("add_b2", "add")):
+        z = np.load(os.path.join(GOLD, f"unett_{tag}.npz"))
+        ref = {k[2:]: tuple(z[k].shape) for k in z.files if k.startswith("w/")}
+        m = UNetT(dim=128, depth=4, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
+                  conv_layers=2, skip_connect_type=skip)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
+        m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}, strict=True)
+
+
 def test_v1_base_layout_and_zero_init():
     from f5e_tts_amd.model import DiT
     m = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)

@@ -130,3 +130,13 @@ def test_gumbel_vq_eval_matches_reference(tag):
     torch.testing.assert_close(r["x"], g["q"], rtol=0, atol=0)
     torch.testing.assert_close(r["code_perplexity"], g["code_perplexity"], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(r["prob_perplexity"], g["prob_perplexity"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,skip", [("concat_b1", "concat"), ("add_b2", "add")])
+def test_unett_forward_matches_reference(tag, skip):
+    z = np.load(os.path.join(GOLD, f"unett_{tag}.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("w/")}
+    for drop in (False, True):
+        out = O.unett_forward(sd, 2, g["x"], g["cond"], g["text"], g["time"], drop, drop, g.get("mask"), skip)
+        torch.testing.assert_close(out, g[f"pred_drop{int(drop)}"], **TOL)
