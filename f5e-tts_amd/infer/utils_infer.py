@@ -257,8 +257,9 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
                 yield w[j: j + chunk_size], target_sample_rate
         return
     # the reference fans chunks out to a thread pool on ONE model (utils_infer.py:511); the engine keeps every
-    # per-call buffer private to the call, so that is safe here
-    with ThreadPoolExecutor(max_workers=1) as ex:
+    # per-call buffer private to the call and captures on a per-thread stream, so that is safe here (SURVEY F12,
+    # tests/test_e2e_gpu.py::test_concurrent_sample_calls_from_two_threads)
+    with ThreadPoolExecutor() as ex:
         results = list(ex.map(process_batch, gen_text_batches))
     waves = [r[0] for r in results]
     specs = [r[1] for r in results]

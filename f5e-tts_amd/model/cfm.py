@@ -48,7 +48,8 @@ class CFM(nn.Module):
         self.use_graph = True  # hipGraph replay of the ODE step; set False to launch eagerly (debugging)
         self.chains = None  # None = auto (parallel CFG-branch chains at small batch); 1 = always one batched forward
         self.kernel_timer = None  # engine.KernelTimer: per-launch HIP-event timing of one op class (eager mode only)
-        self._side_stream = None
+        import threading
+        self._tls = threading.local()  # per-thread capture stream: callers may sample concurrently
 
     @property
     def device(self):
@@ -128,9 +129,9 @@ class CFM(nn.Module):
         if self.use_graph:
             # graph capture needs a non-default stream; order it after the caller's stream and hand back afterwards
             cur = torch.cuda.current_stream(eng.device)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=eng.device)
-            side = self._side_stream
+            side = getattr(self._tls, "stream", None)
+            if side is None:
+                side = self._tls.stream = torch.cuda.Stream(device=eng.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains)

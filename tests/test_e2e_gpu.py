@@ -264,3 +264,25 @@ def test_unett_forward(skip, B):
                 mask.cuda() if mask is not None else None)
         assert out.shape == ref.shape
         assert rel_l2(out, ref) < 1e-2, (skip, drop, rel_l2(out, ref))
+
+
+def test_concurrent_sample_calls_from_two_threads():
+    """The reference fans chunks out to a ThreadPoolExecutor on ONE model (infer/utils_infer.py:511): two
+    threads sampling concurrently (each capturing its own hipGraph on its own stream) must reproduce the sequential
+    results bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    g = torch.Generator().manual_seed(13)
+    jobs = []
+    for i, n in enumerate((70, 101, 83, 64)):
+        cond = torch.randn(1, 30, 100, generator=g).cuda()
+        text = torch.randint(0, 300, (1, 9 + i), generator=g).cuda()
+        jobs.append(dict(cond=cond, text=text, duration=n, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=20 + i))
+    seq = [cfm.sample(**j)[0].clone() for j in jobs]
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            par = list(ex.map(lambda j: cfm.sample(**j)[0].clone(), jobs))
+        torch.cuda.synchronize()
+        for a, b in zip(seq, par):
+            assert torch.equal(a, b)
