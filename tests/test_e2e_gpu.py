@@ -286,3 +286,45 @@ def test_concurrent_sample_calls_from_two_threads():
         torch.cuda.synchronize()
         for a, b in zip(seq, par):
             assert torch.equal(a, b)
+
+
+def test_infer_cli_end_to_end(tmp_path):
+    """infer_cli.main with the reference's flags: yaml arch -> load_model (EMA safetensors checkpoint) -> local Vocos ->
+    infer_process (chunking, duration rule, sample, decode, cross-fade) -> wav on disk."""
+    import yaml
+    from safetensors.torch import save_file
+
+    from f5e_tts_amd.infer import infer_cli, utils_infer as U
+    from f5e_tts_amd.model import DiT
+    from f5e_tts_amd.vocoder import Vocos
+    arch = dict(dim=1024, depth=2, heads=16, ff_mult=2, text_dim=256, conv_layers=1)
+    (tmp_path / "arch.yaml").write_text(yaml.safe_dump({"model": {"arch": dict(arch, checkpoint_activations=False)}}))
+    torch.manual_seed(3)
+    dit = DiT(**arch, text_num_embeds=2545, mel_dim=100)
+    for p in dit.parameters():          # un-zero the AdaLN-zero tensors (SURVEY F8)
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    from f5e_tts_amd.model import CFM
+    full = CFM(transformer=dit).state_dict()
+    sd = {"ema_model." + k: v.contiguous() for k, v in full.items()}
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    vdir = tmp_path / "vocos"
+    vdir.mkdir()
+    (vdir / "config.yaml").write_text(yaml.safe_dump({
+        "backbone": {"init_args": dict(input_channels=100, dim=512, intermediate_dim=1536, num_layers=8)},
+        "head": {"init_args": dict(dim=512, n_fft=1024, hop_length=256, padding="center")}}))
+    voc = Vocos()
+    torch.save(voc.state_dict(), str(vdir / "pytorch_model.bin"))
+    wav = O.synthetic_ref_wave(190)[0].numpy()
+    U.save_wav(str(tmp_path / "ref.wav"), wav * 3.0, 24000)
+    (tmp_path / "cfg.toml").write_text(f'vocoder_local_path = "{vdir}"\nnfe_step = 4\n')
+    infer_cli.main(["-c", str(tmp_path / "cfg.toml"), "-mc", str(tmp_path / "arch.yaml"), "-p",
+                    str(tmp_path / "model.safetensors"), "-r", str(tmp_path / "ref.wav"), "-s", "A short reference text.",
+                    "-t", "Here we generate something, just for test. And a second sentence follows it.",
+                    "-o", str(tmp_path / "out"), "-w", "gen.wav", "--device", "cuda"])
+    out, sr = U.load_wav(str(tmp_path / "out" / "gen.wav"))
+    assert sr == 24000 and out.shape[0] == 1 and torch.isfinite(out).all()
+    ref_secs = len(wav) / 24000
+    gen_bytes, ref_bytes = len("Here we generate something, just for test. And a second sentence follows it."), len("A short reference text. ")
+    expect = ref_secs / ref_bytes * gen_bytes   # duration heuristic (utils_infer.py:455-471), one chunk
+    assert abs(out.shape[1] / 24000 - expect) < 0.25, (out.shape[1] / 24000, expect)
