@@ -96,17 +96,21 @@ def main():
     voc.load_state_dict(vs, strict=False)
     voc = voc.cuda().eval()
     wav = O.synthetic_ref_wave(N_REF, batch=BATCH).cuda()
-    text = O.synthetic_text_ids(N_TOTAL, batch=BATCH).cuda()
+    text = O.synthetic_text_ids(N_TOTAL, batch=BATCH)   # token ids stay on the host, as the reference's callers hand them
 
     def one_pass():
         mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
         return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
 
     log(f"model ready on cuda:{local_rank}, world {world}")
+    latency_ms = None
     for i in range(args.warmup):
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
         one_pass()
         torch.cuda.synchronize()
-        log(f"warmup {i} done")
+        latency_ms = (time.perf_counter() - tw) * 1e3   # one isolated pass, host prep not overlapped
+        log(f"warmup {i} done ({latency_ms:.1f} ms isolated)")
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -204,6 +208,7 @@ def main():
                        "frames_per_step": N_TOTAL * BATCH, "parallelism": f"replica x{world} (utterance sharding, no collective "
                                                                   "on the data path)"},
             "rtf": round(elapsed / gen_audio_s, 5),
+            "isolated_pass_ms": None if latency_ms is None else round(latency_ms, 2),
             "generated_mel_frames_per_sec": round(world * args.steps * BATCH * (N_TOTAL - N_REF) / elapsed, 2),
         }
         if roofline is not None:

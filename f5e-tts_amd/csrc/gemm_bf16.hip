@@ -36,6 +36,7 @@ struct GemmArgs {
   const float* cos_sin;  // [rows_per_seq][32][2]
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
   int tiles_m, tiles_n, m_major;
+  unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* trc = nullptr;
+  if constexpr (DBG == 3) {
+    trc = a.trace + (size_t)blockIdx.x * 48;
+    if (tid == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[1] = __builtin_amdgcn_s_memtime(); }
+  }
 
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
   int bid = blockIdx.x;
@@ -157,17 +163,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   // NSTAGE-deep LDS ring fed by LDS-DMA: NSTAGE-1 K-tiles are in flight while one is consumed.  Counted vmcnt +
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
+  static_assert(NSTAGE >= 2 && NSTAGE <= 8 && (NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
   const int KT = a.K / BK;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < KT) stage(s, s);
   int buf = 0, nbuf = NSTAGE - 1;
+  if constexpr (DBG == 3) { if (tid == 0) trc[2] = __builtin_amdgcn_s_memtime(); }
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = KT - 1 - kt;  // stages issued after tile kt
-    if (NSTAGE >= 4 && rem >= 2) wait_vm_lgkm0<2 * LPT>();
-    else if (NSTAGE >= 3 && rem >= 1) wait_vm_lgkm0<LPT>();
-    else wait_vm_lgkm0<0>();
+    // tile kt must have landed; the min(NSTAGE - 2, rem) younger stages may stay in flight
+    switch (rem < NSTAGE - 2 ? rem : NSTAGE - 2) {
+      case 0: wait_vm_lgkm0<0>(); break;
+      case 1: wait_vm_lgkm0<LPT>(); break;
+      case 2: wait_vm_lgkm0<2 * LPT>(); break;
+      case 3: wait_vm_lgkm0<3 * LPT>(); break;
+      case 4: wait_vm_lgkm0<4 * LPT>(); break;
+      case 5: wait_vm_lgkm0<5 * LPT>(); break;
+      default: wait_vm_lgkm0<6 * LPT>(); break;
+    }
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
+    if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
     if (DBG != 2 && kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
     const char* As = smem + buf * STAGE;
     const char* Ws = As + A_BYTES;
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
 
+  if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
   // ---- epilogue: acc[i][j][r] = C[m = m0+wm0+16j+fr][n = n0+wn0+16i+4fq+r] ----
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -289,9 +306,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       }
     }
   }
+  if constexpr (DBG == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { trc[40] = __builtin_amdgcn_s_memtime(); trc[41] = __builtin_amdgcn_s_memrealtime(); }
+  }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -300,11 +321,11 @@ int launch(GemmArgs& a, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
   if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, 0, WGM, WGN>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, 0, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -320,7 +341,7 @@ int launch_dbg(GemmArgs& a, hipStream_t st) {
 }
 
 // tile_hint: 0 = auto; otherwise tile + 10 * stages with tile 1 = 128x128, 2 = 128x64, 3 = 64x64 and stages in
-// {0 (default for the tile), 2, 3, 4}.
+// {0 (default for the tile), 2, 3, 4} (64x64 also 5, 6, 8).
 template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
@@ -334,7 +355,9 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     else sel = 3;
   }
   // stages: 128x128 wants 2 (64 KiB LDS -> 2 workgroups per CU; measured 386 vs 556 us at M = 60k), small tiles 3
-  if (ns == 0) ns = (sel == 1) ? 2 : 3;
+  // 64x64 with one workgroup per CU and a long K (FF2: K = 2048, weights streaming from HBM): a 4th stage hides the
+  // HBM latency (15.5 -> 12.9 us at M = 938 with HBM-resident weights); at K = 1024 or 3 workgroups per CU it does not pay
+  if (ns == 0) ns = (sel == 1) ? 2 : ((sel == 3 && a.K >= 2048 && blocks(64, 64) <= 256) ? 4 : 3);
   switch (sel * 10 + ns) {
     // 128x128: 8 waves (4 x 2, 32 x 64 per wave), 2 workgroups per CU = 16 waves per CU to cover the per-K-step
     // waits; measured at M = 60k (rocprofv3): QKV 564 vs 710 us, gated residual 324 vs 381, FF1 363 vs 377 for the
@@ -353,8 +376,11 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     case 32: return launch<64, 64, EPI, 2>(a, st);
     case 33: return launch<64, 64, EPI, 3>(a, st);
     case 34: return launch<64, 64, EPI, 4>(a, st);
+    case 35: return launch<64, 64, EPI, 5>(a, st);
+    case 36: return launch<64, 64, EPI, 6>(a, st);
+    case 38: return launch<64, 64, EPI, 8>(a, st);
     case 39: return launch_dbg<EPI, 1>(a, st);   // ablation: LDS-DMA ring + barriers only (results are garbage)
-    case 38: return launch_dbg<EPI, 2>(a, st);   // ablation: ds_read + MFMA + barriers only
+    case 37: return launch_dbg<EPI, 2>(a, st);   // ablation: ds_read + MFMA + barriers only
     default:
       f5e_set_error("gemm_bf16: unknown tile_hint %d", tile_hint);
       return F5E_ERR_BAD_SHAPE;

@@ -176,7 +176,7 @@ class DiTEngine:
         with self._lock:
             hit = self._tables.get(key)
         if hit is None:
-            hit = self.time_tables(t_host.to(self.device))
+            hit = self.time_tables(h2d(t_host, self.device))
             with self._lock:
                 if len(self._tables) >= 8:
                     self._tables.pop(next(iter(self._tables)))
@@ -216,7 +216,7 @@ class DiTEngine:
         if text is None:
             ids = torch.zeros(B, N, dtype=I32, device=dv)
         else:
-            ids = (text.to(dv) + 1)[:, :N]
+            ids = (h2d(text, dv) + 1)[:, :N]
             ids = torch.nn.functional.pad(ids, (0, N - ids.shape[1]), value=0)
             if cfg.text_mask_padding:
                 keep = (ids != 0).to(F32).contiguous()  # mask taken BEFORE the drop (dit.py:62-66)
@@ -387,6 +387,16 @@ class KernelTimer:
             pass
 
 
+def h2d(t: Tensor, device, dtype=None) -> Tensor:
+    """Host tensor -> device through pinned memory, without blocking the host (a pageable hipMemcpyAsync waits for the
+    stream to drain, which would serialise the next call's prep behind the previous call's ODE loop)."""
+    if t.device.type != "cpu":
+        return t.to(device, dtype) if dtype is not None else t.to(device)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
             timer: Optional[KernelTimer] = None, chains: Optional[int] = None) -> Tensor:
     """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint).
@@ -431,8 +441,8 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     rope_cs = engine.rope_table(N)
     seq_len = None
     if inp.seq_len is not None:
-        seq_len = inp.seq_len.to(dv, I32).repeat(nb).contiguous()
-    coef_d = coef.to(dv).contiguous()
+        seq_len = h2d(inp.seq_len, dv, I32).repeat(nb).contiguous()
+    coef_d = h2d(coef, dv).contiguous()
     eval_ptr = torch.zeros(1, dtype=I32, device=dv)
     done = torch.zeros(1, dtype=I32, device=dv)
     n = B * N * mel

@@ -101,6 +101,7 @@ class DiT(nn.Module):
                              long_skip_connection=long_skip_connection, use_ppg=self.use_ppg,
                              ppg_dim=ppg_config.get("ppg_dim", 256) if self.use_ppg else 256)
         self._engine = None
+        self._tensor_list = None
         self.initialize_weights()
 
     def initialize_weights(self):
@@ -116,11 +117,25 @@ class DiT(nn.Module):
     def clear_cache(self):
         self.text_cond, self.text_uncond = None, None
 
+    def invalidate_engine(self):
+        """Call after REPLACING a Parameter object of a sub-module (in-place writes, .to(), load_state_dict are seen)."""
+        self._tensor_list = None
+
+    def _apply(self, fn, *a, **kw):
+        self._tensor_list = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._tensor_list = None
+        return super().load_state_dict(*a, **kw)
+
     # ------------------------------------------------------------------ HIP engine
 
     def engine(self) -> DiTEngine:
         """Repacked device weights; rebuilt when any parameter was replaced or written in place."""
-        tensors = list(self.parameters()) + list(self.buffers())
+        tensors = self._tensor_list
+        if tensors is None:  # the module walk costs ~1 ms: done once, redone after _apply / load_state_dict
+            tensors = self._tensor_list = list(self.parameters()) + list(self.buffers())
         dev = tensors[0].device
         sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(dev),)
         if self._engine is None or self._engine[0] != sig:

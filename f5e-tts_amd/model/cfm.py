@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _C
-from ..engine import SamplerInputs, run_ode
+from ..engine import SamplerInputs, h2d, run_ode
 from .modules import MelSpec
 from .utils import default, exists, intersperse, lens_to_mask, list_str_to_idx, list_str_to_tensor
 
@@ -59,7 +59,8 @@ class CFM(nn.Module):
 
     def _prepare(self, cond, text, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
                  duplicate_test, t_inter, edit_mask, use_text):
-        self.eval()
+        if self.training:  # Module.eval() walks ~2500 sub-modules (2 ms): only when it changes something
+            self.eval()
         dv = self.device
         if dv.type != "cuda":
             raise _C.F5EError(f"CFM lives on {dv}: move it to the GPU (there is no CPU path)")
@@ -68,49 +69,51 @@ class CFM(nn.Module):
             assert cond.shape[-1] == self.num_channels
         cond = cond.to(dv, F32)
         batch, cond_seq_len = cond.shape[:2]
-        if not exists(lens):
-            lens = torch.full((batch,), cond_seq_len, device=dv, dtype=torch.long)
-        lens = lens.to(dv)
+        # Lengths, durations and masks are worked out on the HOST: nothing here waits for the GPU unless the caller
+        # hands lens / duration / token ids as device tensors, so the prep of one call overlaps the ODE loop of the
+        # previous one (the reference syncs at cfm.py:412 `duration.amax()`).
+        lens_h = lens.detach().to("cpu", torch.long) if exists(lens) else torch.full((batch,), cond_seq_len, dtype=torch.long)
         if use_text and isinstance(text, list):
             if exists(self.vocab_char_map):
                 if self.use_align_loss or self.use_cross_mask:
                     text = intersperse(text)
-                text = list_str_to_idx(text, self.vocab_char_map).to(dv)
+                text = list_str_to_idx(text, self.vocab_char_map)
             else:
-                text = list_str_to_tensor(text).to(dv)
+                text = list_str_to_tensor(text)
             assert text.shape[0] == batch
         if not use_text:
             text = None
-        elif exists(text):
-            text = text.to(dv)
-        cond_mask = lens_to_mask(lens)
-        if edit_mask is not None:
-            cond_mask = cond_mask & edit_mask.to(dv)
+        cond_mask = lens_to_mask(lens_h)
         if isinstance(duration, int):
-            duration = torch.full((batch,), duration, device=dv, dtype=torch.long)
-        duration = duration.to(dv)
-        if text is not None:
-            duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)
+            dur_h = torch.full((batch,), duration, dtype=torch.long)
         else:
-            duration = torch.maximum(lens + 1, duration)
-        duration = duration.clamp(max=max_duration)
-        n = int(duration.amax())
+            dur_h = duration.detach().to("cpu", torch.long)
+        if text is not None:
+            text_h = text.detach().to("cpu")
+            dur_h = torch.maximum(torch.maximum((text_h != -1).sum(dim=-1), lens_h) + 1, dur_h)
+            text = h2d(text, dv)
+        else:
+            dur_h = torch.maximum(lens_h + 1, dur_h)
+        dur_h = dur_h.clamp(max=max_duration)
+        n = int(dur_h.amax())
         test_cond = None
         if duplicate_test:
             test_cond = F.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
         cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
         if no_ref_audio:
             cond = torch.zeros_like(cond)
-        cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False).unsqueeze(-1)
+        if edit_mask is not None:
+            cond_mask = h2d(cond_mask, dv) & edit_mask.to(dv)
+        cond_mask = h2d(F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False), dv).unsqueeze(-1)
         step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond)).contiguous()
-        seq_len = duration.to(I32) if batch > 1 else None  # reference: mask = None for single inference (cfm.py:425-428)
+        seq_len = dur_h.to(I32) if batch > 1 else None  # reference: mask = None for single inference (cfm.py:425-428)
         # seeded noise, one item at a time, CPU generator (cfm.py:452-457)
         y0 = torch.zeros(batch, n, self.num_channels, dtype=F32)
-        for i, dur in enumerate(duration.tolist()):
+        for i, dur in enumerate(dur_h.tolist()):
             if exists(seed):
                 torch.manual_seed(seed)
             y0[i, :dur] = torch.randn(dur, self.num_channels, dtype=F32)
-        y0 = y0.to(dv)
+        y0 = h2d(y0, dv)
         t_start = 0
         if duplicate_test:
             t_start = t_inter

@@ -1,0 +1,129 @@
+// Per-workgroup timeline of the bf16 GEMM kernel (diagnostic build, DBG == 3 stamps) inside a chain of dependent
+// launches replayed from a hipGraph.  Answers: where do the microseconds of a small-M launch go (launch gap, start
+// ramp, first tile, K loop, epilogue)?    usage: gemm_trace.bin <variant> <M> <N> <K> <epi: 0 bf16, 1 gelu, 2 gate_res>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../f5e-tts_amd/csrc/gemm_bf16.hip"
+
+void f5e_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+}
+
+template <int EPI>
+static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
+  switch (v) {
+    case 0: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 2, 3>(a, st);
+    case 1: *bm = 128; *bn = 64; return launch<128, 64, EPI, 3, 2, 2, 3>(a, st);
+    case 2: *bm = 128; *bn = 128; return launch<128, 128, EPI, 2, 4, 2, 3>(a, st);
+    case 3: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3>(a, st);
+    case 4: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 2, 2, 3>(a, st);
+    case 5: *bm = 64; *bn = 64; return launch<64, 64, EPI, 2, 2, 2, 3>(a, st);
+  }
+  return -1;
+}
+
+static double med(std::vector<double> v) {
+  if (v.empty()) return 0;
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
+}
+
+int main(int argc, char** argv) {
+  const int variant = argc > 1 ? atoi(argv[1]) : 0;
+  const int M = argc > 2 ? atoi(argv[2]) : 938, N = argc > 3 ? atoi(argv[3]) : 1024, K = argc > 4 ? atoi(argv[4]) : 1024;
+  const int epi = argc > 5 ? atoi(argv[5]) : 2;
+  const int NW = 22, L = 44;
+  bf16 *A, *W, *out;
+  float *bias, *resid, *gate;
+  unsigned long long* trace;
+  const size_t max_grid = 4096;
+  hipMalloc(&A, (size_t)M * K * 2);
+  hipMalloc(&W, (size_t)NW * N * K * 2);
+  hipMalloc(&out, (size_t)M * N * 2);
+  hipMalloc(&bias, N * 4);
+  hipMalloc(&gate, N * 4);
+  hipMalloc(&resid, (size_t)M * N * 4);
+  hipMalloc(&trace, (size_t)L * max_grid * 48 * 8);
+  {  // small random-ish fill (values do not matter for timing, but keep them finite)
+    std::vector<unsigned short> h((size_t)NW * N * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 25);  // ~[0.0078, 0.0156]
+    hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+    hipMemset(bias, 0, N * 4);
+    hipMemset(gate, 0, N * 4);
+    hipMemset(resid, 0, (size_t)M * N * 4);
+  }
+  hipStream_t st;
+  hipStreamCreate(&st);
+  int bm = 0, bn = 0, grid = 0;
+  auto one = [&](int l) {
+    GemmArgs a{};
+    a.A = A; a.lda = K; a.W = W + (size_t)(l % NW) * N * K; a.ldw = K; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = N;
+    a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = M;
+    a.trace = trace + (size_t)l * max_grid * 48;
+    int rc = epi == 2 ? run_variant<EPI_GATE_RES>(variant, a, st, &bm, &bn)
+                      : (epi == 1 ? run_variant<EPI_BF16_GELU>(variant, a, st, &bm, &bn) : run_variant<EPI_BF16>(variant, a, st, &bm, &bn));
+    grid = a.tiles_m * a.tiles_n;
+    return rc;
+  };
+  if (one(0) != 0 || (size_t)grid > max_grid) { fprintf(stderr, "bad variant / grid\n"); return 1; }
+  hipStreamSynchronize(st);
+  hipGraph_t g; hipGraphExec_t ge;
+  hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+  for (int l = 0; l < L; ++l) one(l);
+  hipStreamEndCapture(st, &g);
+  hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  for (int r = 0; r < 4; ++r) hipGraphLaunch(ge, st);
+  hipStreamSynchronize(st);
+  std::vector<unsigned long long> h((size_t)L * max_grid * 48);
+  hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost);
+  const int KT = K / 64;
+  std::vector<double> gap, ramp, span, first, iter, loop, epil, wg_total, clk;
+  for (int l = 12; l < L; ++l) {
+    auto T = [&](int wg, int slot) { return h[((size_t)l * max_grid + wg) * 48 + slot]; };
+    auto P = [&](int wg, int slot) { return h[((size_t)(l - 1) * max_grid + wg) * 48 + slot]; };
+    unsigned long long s_min = ~0ull, s_max = 0, e_max = 0, pe_max = 0;
+    for (int w = 0; w < grid; ++w) {
+      s_min = std::min(s_min, T(w, 0)); s_max = std::max(s_max, T(w, 0)); e_max = std::max(e_max, T(w, 41));
+      pe_max = std::max(pe_max, P(w, 41));
+      first.push_back((double)(T(w, 4) - T(w, 1)));
+      iter.push_back((double)(T(w, 4 + std::min(KT, 36) - 1) - T(w, 4)) / (std::min(KT, 36) - 1));
+      loop.push_back((double)(T(w, 3) - T(w, 4)));
+      epil.push_back((double)(T(w, 40) - T(w, 3)));
+      wg_total.push_back((double)(T(w, 40) - T(w, 1)));
+      const double rt = (double)(T(w, 41) - T(w, 0));
+      if (rt > 0) clk.push_back((double)(T(w, 40) - T(w, 1)) / rt * 100.0);  // MHz
+    }
+    gap.push_back(((double)s_min - (double)pe_max) * 10.0);
+    ramp.push_back((double)(s_max - s_min) * 10.0);
+    span.push_back((double)(e_max - s_min) * 10.0);
+  }
+  const double mhz = med(clk);
+  printf("variant %d tile %dx%d M=%d N=%d K=%d epi=%d grid=%d  shader clock ~%.0f MHz\n", variant, bm, bn, M, N, K, epi, grid, mhz);
+  printf("  per launch [ns]: gap after previous kernel's last end -> first start %.0f | start ramp (first->last workgroup) %.0f | span first start -> last end %.0f\n",
+         med(gap), med(ramp), med(span));
+  printf("  per workgroup [cycles, median]: entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
+         med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
+  {  // distribution of per-workgroup start offsets and totals for the last launch
+    const int l = L - 1;
+    std::vector<double> so, tot;
+    unsigned long long s_min = ~0ull;
+    for (int w = 0; w < grid; ++w) s_min = std::min(s_min, h[((size_t)l * max_grid + w) * 48]);
+    for (int w = 0; w < grid; ++w) {
+      so.push_back((double)(h[((size_t)l * max_grid + w) * 48] - s_min) * 10.0);
+      tot.push_back((double)(h[((size_t)l * max_grid + w) * 48 + 41] - h[((size_t)l * max_grid + w) * 48]) * 10.0);
+    }
+    std::sort(so.begin(), so.end()); std::sort(tot.begin(), tot.end());
+    printf("  last launch: start offset ns p10 %.0f p50 %.0f p90 %.0f max %.0f | workgroup lifetime ns p10 %.0f p50 %.0f p90 %.0f max %.0f\n",
+           so[grid / 10], so[grid / 2], so[grid * 9 / 10], so[grid - 1], tot[grid / 10], tot[grid / 2], tot[grid * 9 / 10], tot[grid - 1]);
+  }
+  return 0;
+}

@@ -8,7 +8,7 @@ BF = torch.bfloat16
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 469
 M, D, FF, H = S * N, 1024, 2048, 16
-NWS, ROUNDS = 22, 5
+NWS, ROUNDS = int(os.environ.get("NWS", "22")), int(os.environ.get("ROUNDS", "5"))
 npad = (N + 63) // 64 * 64
 dev = "cuda"
 x = torch.randn(M, D, device=dev); hn = torch.empty(M, D, device=dev, dtype=BF)
