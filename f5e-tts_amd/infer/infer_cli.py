@@ -108,8 +108,6 @@ def main(argv=None):
     if s["gen_file"]:
         with open(s["gen_file"], "r", encoding="utf-8") as f:
             s["gen_text"] = f.read()
-    if s["remove_silence"]:
-        raise NotImplementedError("--remove_silence needs pydub (out of scope, SURVEY section 8)")
     from ..model import DiT
     vocoder = U.load_vocoder(s["vocoder_name"], is_local=True,
                              local_path=config.get("vocoder_local_path", "pretrained_models/vocos-mel-24khz"),
@@ -118,6 +116,8 @@ def main(argv=None):
                          vocab_file=s["vocab_file"], device=s["device"])
     voices = dict(config.get("voices", {}))
     voices["main"] = {"ref_audio": s["ref_audio"], "ref_text": s["ref_text"]}
+    for v in voices.values():   # reference infer_cli.py:297-303
+        v["ref_audio"], v["ref_text"] = U.preprocess_ref_audio_text(v["ref_audio"], v["ref_text"])
     segments = []
     for voice, text in split_voices(s["gen_text"]):
         v = voices.get(voice, voices["main"])
@@ -134,6 +134,8 @@ def main(argv=None):
         os.makedirs(s["output_dir"], exist_ok=True)
         path = os.path.join(s["output_dir"], s["output_file"])
         U.save_wav(path, np.concatenate(segments), U.target_sample_rate)
+        if s["remove_silence"]:
+            U.remove_silence_for_generated_wav(path)
         print(path)
 
 

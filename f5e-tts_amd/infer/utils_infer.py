@@ -3,14 +3,17 @@
 cross-fade rules.  Everything between ``model_obj.sample`` and ``vocoder.decode`` runs on libf5e_hip.so; what is left
 here is host glue (text chunking, wav I/O, numpy cross-fade) exactly as in the reference.
 
-Not rebuilt (out of scope): pydub silence trimming + Whisper ASR of ``preprocess_ref_audio_text``,
+Resampling and the pydub-style silence clipping live in ``infer/audio.py``.  Not rebuilt (out of scope,
+SURVEY section 8): the Whisper ASR fallback of ``preprocess_ref_audio_text`` (an empty ``ref_text`` is an error here),
 the bigvgan vocoder, HF-hub downloads (no network).  Chinese g2p needs the optional ``jieba`` + ``pypinyin`` packages;
 the ASCII path is self-contained.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import re
+import tempfile
 import wave
 from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Tuple
@@ -21,6 +24,7 @@ import torch
 from ..model import CFM
 from ..model.utils import get_tokenizer
 from ..vocoder import Vocos, load_vocos
+from . import audio as A
 
 # ----------------------------------------- defaults (reference infer/utils_infer.py:49-62)
 device = "cuda" if torch.cuda.is_available() else "cpu"
@@ -191,6 +195,51 @@ def save_wav(path: str, audio: np.ndarray, sr: int) -> None:
         w.writeframes(pcm.tobytes())
 
 
+def _read_segment(path: str) -> A.Segment:
+    wav, sr = load_wav(path)
+    return A.Segment.from_float(wav.numpy(), sr)
+
+
+def _write_segment(path: str, seg: A.Segment) -> None:
+    with wave.open(path, "wb") as w:
+        w.setnchannels(seg.pcm.shape[1])
+        w.setsampwidth(2)
+        w.setframerate(seg.rate)
+        w.writeframes(np.ascontiguousarray(seg.pcm, dtype="<i2").tobytes())
+
+
+_ref_audio_cache = {}
+
+
+def preprocess_ref_audio_text(ref_audio_orig, ref_text, clip_short=True, show_info=print):
+    """Reference infer/utils_infer.py:293-352: clip the clip to <= 12 s at silences, strip silent edges, add 50 ms of
+    silence, write a temporary wav; make ref_text end in ". ".  Returns (wav path, ref_text)."""
+    show_info("Converting audio...")
+    seg = A.clip_reference(_read_segment(ref_audio_orig), clip_short=clip_short, note=show_info)
+    with tempfile.NamedTemporaryFile(delete=False, suffix=".wav") as f:
+        ref_audio = f.name
+    _write_segment(ref_audio, seg)
+    with open(ref_audio, "rb") as fh:
+        audio_hash = hashlib.md5(fh.read()).hexdigest()
+    if not ref_text.strip():
+        if audio_hash in _ref_audio_cache:
+            show_info("Using cached reference text...")
+            ref_text = _ref_audio_cache[audio_hash]
+        else:
+            raise ValueError("ref_text is empty: the reference falls back to Whisper ASR here (utils_infer.py:341), "
+                             "which is outside this build; pass the transcript of the reference audio")
+    else:
+        show_info("Using custom reference text...")
+    if not ref_text.endswith(". ") and not ref_text.endswith("\u3002"):
+        ref_text += " " if ref_text.endswith(".") else ". "
+    return ref_audio, ref_text
+
+
+def remove_silence_for_generated_wav(filename):
+    """Reference infer/utils_infer.py:567-575."""
+    _write_segment(filename, A.strip_generated_silence(_read_segment(filename)))
+
+
 def cross_fade_concat(waves: List[np.ndarray], cross_fade_duration: float, sr: int = target_sample_rate) -> np.ndarray:
     """Linear cross-fade between consecutive chunk waves (reference utils_infer.py:520-556)."""
     if cross_fade_duration <= 0:
@@ -231,7 +280,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     if rms < target_rms:
         audio = audio * target_rms / rms
     if sr != target_sample_rate:
-        raise NotImplementedError(f"reference audio must be {target_sample_rate} Hz (resampler is SURVEY row f2)")
+        audio = A.resample(audio, sr, target_sample_rate)
     audio = audio.to(device)
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "

@@ -288,7 +288,8 @@ def test_concurrent_sample_calls_from_two_threads():
             assert torch.equal(a, b)
 
 
-def test_infer_cli_end_to_end(tmp_path):
+@pytest.mark.parametrize("ref_sr", [24000, 16000])
+def test_infer_cli_end_to_end(tmp_path, ref_sr):
     """infer_cli.main with the reference's flags: yaml arch -> load_model (EMA safetensors checkpoint) -> local Vocos ->
     infer_process (chunking, duration rule, sample, decode, cross-fade) -> wav on disk."""
     import yaml
@@ -316,7 +317,7 @@ def test_infer_cli_end_to_end(tmp_path):
     voc = Vocos()
     torch.save(voc.state_dict(), str(vdir / "pytorch_model.bin"))
     wav = O.synthetic_ref_wave(190)[0].numpy()
-    U.save_wav(str(tmp_path / "ref.wav"), wav * 3.0, 24000)
+    U.save_wav(str(tmp_path / "ref.wav"), wav * 3.0, ref_sr)    # 16 kHz: goes through the sinc resampler
     (tmp_path / "cfg.toml").write_text(f'vocoder_local_path = "{vdir}"\nnfe_step = 4\n')
     infer_cli.main(["-c", str(tmp_path / "cfg.toml"), "-mc", str(tmp_path / "arch.yaml"), "-p",
                     str(tmp_path / "model.safetensors"), "-r", str(tmp_path / "ref.wav"), "-s", "A short reference text.",
@@ -324,7 +325,7 @@ def test_infer_cli_end_to_end(tmp_path):
                     "-o", str(tmp_path / "out"), "-w", "gen.wav", "--device", "cuda"])
     out, sr = U.load_wav(str(tmp_path / "out" / "gen.wav"))
     assert sr == 24000 and out.shape[0] == 1 and torch.isfinite(out).all()
-    ref_secs = len(wav) / 24000
-    gen_bytes, ref_bytes = len("Here we generate something, just for test. And a second sentence follows it."), len("A short reference text. ")
+    ref_secs = len(wav) / ref_sr + 0.05      # preprocess_ref_audio_text appends 50 ms of silence
+    gen_bytes, ref_bytes = len("Here we generate something, just for test. And a second sentence follows it."), len("A short reference text.  ")   # ". " rule of preprocess_ref_audio_text, then the trailing-space rule (:452)
     expect = ref_secs / ref_bytes * gen_bytes   # duration heuristic (utils_infer.py:455-471), one chunk
     assert abs(out.shape[1] / 24000 - expect) < 0.25, (out.shape[1] / 24000, expect)
