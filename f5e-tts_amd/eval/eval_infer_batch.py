@@ -131,13 +131,22 @@ def main(argv=None):
     p.add_argument("--vocoder_path", default="pretrained_models/vocos-mel-24khz")
     p.add_argument("--output_dir", default="")
     p.add_argument("--partition", default="lpt", choices=["lpt", "contiguous"])
+    # the three drivers of the reference in one: eval_infer_batch.py (cfg), eval_infer_batch_tts.py (-as/-at) and
+    # eval_infer_batch_vc.py (-as/-ap; PPG read from --ppg_dir/<gen_utt>.npy, the wenet extractor is SURVEY row f3)
+    p.add_argument("--mode", default="cfg", choices=["cfg", "tts", "vc"])
+    p.add_argument("-as", "--alpha_spk", default=2.5, type=float)
+    p.add_argument("-at", "--alpha_txt", default=3, type=float)
+    p.add_argument("-ap", "--alpha_ppg", default=3, type=float)
+    p.add_argument("-mc", "--model_cfg", default="", help="model yaml (default configs/<expname>.yaml of this package)")
+    p.add_argument("--ppg_dir", default="", help="vc mode: directory of <gen_utt>.npy PPG arrays [frames, ppg_dim]")
     args = p.parse_args(argv)
 
     import torch.distributed as dist
 
     from ..infer import utils_infer as U
-    from ..infer.infer_cli import load_arch
-    from ..model import DiT
+    from ..model import CFM, DiT
+    from ..model.utils import get_tokenizer
+    from ..train.parse_cfg import parse_model_yaml
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,11 +157,28 @@ def main(argv=None):
         dist.init_process_group("nccl")
     device = f"cuda:{local}"
     ckpt = args.ckpt or f"ckpts/{args.expname}/model_{args.ckptstep}.pt"
-    model = U.load_model(DiT, load_arch(args.expname, ""), ckpt, ode_method=args.odemethod, device=device)
+    import yaml
+    cfg_path = args.model_cfg or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                                              f"{args.expname}.yaml")
+    with open(cfg_path, "r") as f:
+        mc = parse_model_yaml(yaml.safe_load(f))
+    if args.mode == "vc" and not mc["transformer_ppg_config"]["use_ppg"]:
+        raise SystemExit("--mode vc needs a model with use_ppg: True")
+    vocab_char_map, vocab_size = get_tokenizer(U._DEFAULT_VOCAB)
+    model = CFM(transformer=DiT(**mc["arch"], text_num_embeds=vocab_size, mel_dim=U.n_mel_channels,
+                                ppg_config=mc["transformer_ppg_config"], cb_config=mc["transformer_codebook_config"]),
+                mel_spec_kwargs=dict(n_fft=U.n_fft, hop_length=U.hop_length, win_length=U.win_length,
+                                     n_mel_channels=U.n_mel_channels, target_sample_rate=U.target_sample_rate,
+                                     mel_spec_type="vocos"),
+                odeint_kwargs=dict(method=args.odemethod), vocab_char_map=vocab_char_map,
+                ppg_config=mc["cfm_ppg_config"], cb_config=mc["cfm_codebook_config"]).to(device)
+    model = U.load_checkpoint(model, ckpt, device, use_ema=True)
     vocoder = U.load_vocoder("vocos", is_local=True, local_path=args.vocoder_path, device=device)
     out_dir = args.output_dir or (f"results/{args.expname}_{args.ckptstep}/{os.path.basename(args.testset)}/"
                                   f"seed{args.seed}_{args.odemethod}_nfe{args.nfestep}_vocos_ss{args.swaysampling}"
-                                  "_cfg2.0_speed1.0")
+                                  + {"cfg": "_cfg2.0_speed1.0",
+                                     "tts": f"_alpha_spk{args.alpha_spk}_txt{args.alpha_txt}_speed1.0",
+                                     "vc": f"_alpha_spk{args.alpha_spk}_ppg{args.alpha_ppg}_speed1.0"}[args.mode])
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     rows = []
@@ -183,9 +209,18 @@ def main(argv=None):
         text = U.convert_char_to_pinyin([ref_txt + gen_txt])
         with torch.inference_mode():
             ref_mel = model.mel_spec(audio.to(device)).permute(0, 2, 1)[:, :ref_len]
-            gen, _ = model.sample(cond=ref_mel, text=text, duration=torch.tensor([tot]), lens=torch.tensor([ref_len]),
-                                  steps=args.nfestep, cfg_strength=2.0, sway_sampling_coef=args.swaysampling,
-                                  seed=args.seed)
+            kw = dict(duration=torch.tensor([tot]), steps=args.nfestep, sway_sampling_coef=args.swaysampling,
+                      seed=args.seed)
+            if args.mode == "cfg":      # reference eval_infer_batch.py:196-206
+                gen, _ = model.sample(cond=ref_mel, text=text, lens=torch.tensor([ref_len]), cfg_strength=2.0, **kw)
+            elif args.mode == "tts":    # reference eval_infer_batch_tts.py:203-214
+                gen, _ = model.sample_tts(cond=ref_mel, text=text, lens=torch.tensor([ref_len]),
+                                          alpha_spk=args.alpha_spk, alpha_txt=args.alpha_txt, **kw)
+            else:                       # reference eval_infer_batch_vc.py:214-224
+                import numpy as np
+                ppg = torch.from_numpy(np.load(os.path.join(args.ppg_dir, utt + ".npy")).astype("float32"))[None]
+                gen, _ = model.sample_vc(cond=ref_mel, ppg=ppg.to(device), alpha_spk=args.alpha_spk,
+                                         alpha_ppg=args.alpha_ppg, **kw)
             wav = vocoder.decode(gen[:, ref_len:tot].permute(0, 2, 1).float())
         if rms < U.target_rms:
             wav = wav * rms / U.target_rms

@@ -10,7 +10,8 @@ from torch import nn
 
 from ... import _C
 from ...engine import DiTConfig, DiTEngine
-from ..modules import (AdaLayerNorm_Final, ConvNeXtV2Block, ConvPositionEmbedding, DiTBlock, TimestepEmbedding)
+from ..modules import (AdaLayerNorm_Final, ConvNeXtV2Block, ConvPositionEmbedding, DiTBlock, GumbelVectorQuantizer,
+                       TimestepEmbedding)
 
 F32, I32 = torch.float32, torch.int32
 
@@ -82,9 +83,14 @@ class DiT(nn.Module):
                                           transformer_config=ppg_config.get("transformer_config", dict()))
         self.use_codebook = bool(cb_config["use_codebook"])
         if self.use_codebook:
-            # training-only in the reference: DiT.sample never touches the quantizer
-            raise _C.F5EError("use_codebook builds a training-only quantizer; load such checkpoints with "
-                              "cb_config=dict(use_codebook=False) and strict=False (inference does not use it)")
+            # Owned for state_dict compatibility (strict checkpoint loads) and as the parity-only eval op; the reference
+            # applies it in the training forward only, DiT.sample never touches it (dit.py:296-308)
+            self.quantizer = GumbelVectorQuantizer(
+                dim=text_dim, num_vars=cb_config["num_vars"],
+                temp=(cb_config["temp_start"], cb_config["temp_stop"], cb_config["temp_decay"]),
+                groups=cb_config["groups"], combine_groups=cb_config["combine_groups"], vq_dim=text_dim,
+                time_first=True, weight_proj_depth=cb_config["weight_proj_depth"],
+                weight_proj_factor=cb_config["weight_proj_factor"])
         self.input_embed = InputEmbedding(mel_dim, text_dim, dim, self.use_ppg)
         self.rotary_embed = RotaryEmbedding(dim_head)
         self.dim, self.depth = dim, depth

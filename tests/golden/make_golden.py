@@ -474,9 +474,33 @@ def make_vq_case(modules_mod):
     print("wrote", path)
 
 
+def make_layouts(dit_mod):
+    """state_dict key -> shape of the full-size models as the REFERENCE constructs them (no weights: names and shapes
+    are what `load_checkpoint(strict=True)` needs): F5TTS_v1_Base, and BASELINE config 5 (Small + PPG + codebook)."""
+    import json
+    base = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545, mel_dim=100)
+    small = dict(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4,
+                 pe_attn_head=1, text_num_embeds=2545, mel_dim=100,
+                 ppg_config=dict(use_ppg=True, ppg_dim=256, use_cross_mask=False, cross_mask_config={},
+                                 use_transformer=False, transformer_config={}),
+                 cb_config=dict(use_codebook=True, num_vars=100, temp_start=2, temp_stop=0.5, temp_decay=0.999995,
+                                groups=2, combine_groups=False, weight_proj_depth=1, weight_proj_factor=1,
+                                use_perplex_loss=False, perplex_loss_config={}, use_align_loss=False,
+                                align_loss_config={}))
+    out = {}
+    for tag, kw in (("v1_base", base), ("small_ppg_codebook", small)):
+        out[tag] = {k: list(v.shape) for k, v in dit_mod.DiT(**kw).state_dict().items()}
+    with open(os.path.join(HERE, "layouts.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("layouts.json", {k: len(v) for k, v in out.items()})
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     modules_mod, dit_mod, cfm_mod, utils_mod = load_reference(ref)
+    if len(sys.argv) > 2 and sys.argv[2] == "layouts":
+        make_layouts(dit_mod)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "callers":
         make_callers_case(ref, cfm_mod)
         return
@@ -501,6 +525,7 @@ def main():
     make_callers_case(ref, cfm_mod)
     make_vq_case(modules_mod)
     make_unett_case()
+    make_layouts(dit_mod)
 
 
 if __name__ == "__main__":

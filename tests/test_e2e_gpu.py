@@ -2,6 +2,8 @@
 inputs.  The network runs bf16 MFMA contractions with fp32 residual stream / statistics / ODE state, the oracle is
 fp32 throughout; tolerances (stated per test) are relative L2 and max-abs on the mel, measured against the spread of
 the reference output."""
+import os
+
 import pytest
 import torch
 
@@ -176,6 +178,37 @@ def test_small_ppg_config_c5_shape():
         o, t = cfm.sample_tts(cond.cuda(), text.cuda(), alpha_spk=2.5, alpha_txt=3.0, **kw)
         ro, rt = O.cfm_sample(sd, cfg, cond, text, None, mode="tts", alpha_a=2.5, alpha_b=3.0, **kw)
         assert rel_l2(t[-1], rt[-1]) < 2e-2, (extra, rel_l2(t[-1], rt[-1]))
+
+
+def test_codebook_model_samples_like_the_same_model_without_quantizer():
+    """BASELINE config 5 names the Gumbel codebook: DiT owns `quantizer.*` (strict checkpoint loads) but, as in the
+    reference (dit.py:417-472), sample never applies it -> bit-identical to the model built without it."""
+    import yaml
+
+    import f5e_tts_amd
+    from f5e_tts_amd.model import CFM, DiT
+    from f5e_tts_amd.train.parse_cfg import parse_model_yaml
+    path = os.path.join(os.path.dirname(os.path.abspath(f5e_tts_amd.__file__)), "configs", "F5TTS_Small_PPG.yaml")
+    mc = parse_model_yaml(yaml.safe_load(open(path)))
+    arch = dict(mc["arch"], depth=2, text_num_embeds=300, mel_dim=100)
+    torch.manual_seed(21)
+    with_cb = DiT(**arch, ppg_config=mc["transformer_ppg_config"], cb_config=mc["transformer_codebook_config"])
+    for p in with_cb.parameters():
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    without = DiT(**arch, ppg_config=mc["transformer_ppg_config"])
+    without.load_state_dict({k: v for k, v in with_cb.state_dict().items() if not k.startswith("quantizer.")})
+    g = torch.Generator().manual_seed(3)
+    cond, ppg = torch.randn(1, 30, 100, generator=g).cuda(), torch.randn(1, 45, 256, generator=g).cuda()
+    outs = []
+    for dit in (with_cb, without):
+        cfm = CFM(transformer=dit, ppg_config=mc["cfm_ppg_config"]).cuda().eval()
+        outs.append(cfm.sample_vc(cond, ppg, duration=72, steps=3, alpha_spk=2.5, alpha_ppg=3.0,
+                                  sway_sampling_coef=-1.0, seed=1)[0])
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 1e-3
+    assert torch.equal(outs[0], outs[1])
+    q = with_cb.quantizer.cuda()(torch.randn(2, 7, 512, device="cuda"))    # the eval op itself stays callable
+    assert q["x"].shape == (2, 7, 512) and "code_perplexity" in q
 
 
 def test_sampler_flags_and_edges():

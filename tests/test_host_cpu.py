@@ -277,3 +277,21 @@ def test_sharded_driver_world2_gloo(tmp_path):
     total = sum(300 + 53 * (i % 7) for i in range(13))
     assert r[0]["frames"] == r[1]["frames"] == total                   # SUM all-reduce
     assert r[0]["seconds"] == r[1]["seconds"] > 0                      # MAX all-reduce
+
+
+def test_full_size_layouts_match_reference_including_codebook():
+    """F5TTS_v1_Base and BASELINE config 5 (Small + PPG + Gumbel codebook) built from this package's yaml files have
+    exactly the reference's state_dict names and shapes (tests/golden/layouts.json, written by the reference)."""
+    import yaml
+
+    import f5e_tts_amd
+    from f5e_tts_amd.model import DiT
+    from f5e_tts_amd.train.parse_cfg import parse_model_yaml
+    ref = json.load(open(os.path.join(GOLD, "layouts.json")))
+    cfgdir = os.path.join(os.path.dirname(os.path.abspath(f5e_tts_amd.__file__)), "configs")
+    for tag, name in (("v1_base", "F5TTS_v1_Base"), ("small_ppg_codebook", "F5TTS_Small_PPG")):
+        mc = parse_model_yaml(yaml.safe_load(open(os.path.join(cfgdir, name + ".yaml"))))
+        m = DiT(**mc["arch"], text_num_embeds=2545, mel_dim=100, ppg_config=mc["transformer_ppg_config"],
+                cb_config=mc["transformer_codebook_config"])
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref[tag], tag
+    assert len(ref["v1_base"]) == 364 and any(k.startswith("quantizer.") for k in ref["small_ppg_codebook"])
