@@ -19,6 +19,10 @@ SIGNATURES = {
     "f5e_gemm_bf16_bias": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "f5e_gemm_bf16_gate_residual": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I],
     "f5e_gemm_bf16_qkv_rope": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_gemm_bf16_bias_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "f5e_gemm_bf16_gate_residual_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P],
+    "f5e_gemm_bf16_qkv_rope_ln": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "f5e_adaln_pre": [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I],
     "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
     "f5e_grn": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
@@ -55,6 +59,13 @@ class BlockWeights(C.Structure):
                                   "q_norm_w", "k_norm_w")]
 
 
+class LnFuse(C.Structure):
+    """f5e_ln_fuse: one side (consumer: stats..eps, producer: xs_out..stats_out) is filled per launch."""
+    _fields_ = [("stats", _P), ("parts", _I), ("c", _P), ("d", _P), ("cd_stride", _I), ("cd_rows", _I),
+                ("cd_eval_stride", _I), ("eval_ptr", _P), ("rows_per_seq", _I), ("eps", _F),
+                ("xs_out", _P), ("ld_xs", _I), ("next_scale", _P), ("stats_out", _P)]
+
+
 class DitPlan(C.Structure):
     _fields_ = (
         [(n, _I) for n in ("S", "B", "N", "n_pad", "D", "H", "rope_heads", "FF", "L", "mel", "mod_rows")]
@@ -65,6 +76,7 @@ class DitPlan(C.Structure):
         + [("w_skip", _P), ("skip_res", _P), ("skip_tmp", _P)]
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
         + [("timer", _P), ("timer_op", _I)]
+        + [("fuse_ln", _I), ("ln_stats", _P), ("cd", _P), ("cd_stride", _I)]
     )
 
 OP_NONE, OP_INPROJ, OP_CONVPOS, OP_LN, OP_QKV, OP_ATTN, OP_OUT, OP_FF1, OP_FF2, OP_FINAL = range(10)

@@ -36,6 +36,13 @@ void f5e_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// A device-side scalar that a PREVIOUS launch wrote (the ODE evaluation counter): read it through the constant address
+// space so it becomes an s_load (scalar cache, invalidated at kernel start) instead of a vector load, whose
+// s_waitcnt vmcnt(0) would drain every LDS-DMA already in flight and serialise the dependent table loads behind it.
+__device__ __forceinline__ int load_uniform_i32(const int* p) {
+  return *(const __attribute__((address_space(4))) int*)(uintptr_t)p;
+}
+
 __device__ __forceinline__ bf16x4 f2bf4(float a, float b, float c, float d) {
   f32x4 v = {a, b, c, d};
   return __builtin_convertvector(v, bf16x4);

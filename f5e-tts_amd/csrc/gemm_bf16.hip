@@ -37,6 +37,14 @@ struct GemmArgs {
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
   int tiles_m, tiles_n, m_major;
   unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
+  // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
+  //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
+  //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - mean c[n]) + d[n]
+  //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
+  //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
+  const float* ln_stats; int ln_parts;
+  const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
+  bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
@@ -52,7 +60,20 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2>
+template <int LPT, int EXTRA>
+__device__ __forceinline__ void wait_stages(int nst) {
+  switch (nst) {
+    case 0: wait_vm_lgkm0<EXTRA>(); break;
+    case 1: wait_vm_lgkm0<LPT + EXTRA>(); break;
+    case 2: wait_vm_lgkm0<2 * LPT + EXTRA>(); break;
+    case 3: wait_vm_lgkm0<3 * LPT + EXTRA>(); break;
+    case 4: wait_vm_lgkm0<4 * LPT + EXTRA>(); break;
+    case 5: wait_vm_lgkm0<5 * LPT + EXTRA>(); break;
+    default: wait_vm_lgkm0<6 * LPT + EXTRA>(); break;
+  }
+}
+
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int NT = 64 * WGM * WGN;  // threads: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
@@ -130,36 +151,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Epilogue operands are fetched NOW so their (cold-cache) latency hides under the K loop: bias always, and for the
-  // gated-residual epilogue also the gate row and the fp32 residual tile.  Only for small tiles (register budget).
-  constexpr bool PREF = (TM * TN <= 4);
-  f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
-  bool pf_live[PREF ? TM : 1];
-  if (PREF) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = n0 + wn0 + i * 16 + fq * 4;
-      pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (EPI == EPI_GATE_RES) {
-      const size_t eoff = a.eval_ptr ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm0 + j * 16 + fr;
-        const int seq = m / a.rows_per_seq, pos = m - seq * a.rows_per_seq;
-        pf_live[j] = (m < a.M) && ((a.seq_len == nullptr) || (pos < a.seq_len[seq]));
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int n = n0 + wn0 + i * 16 + fq * 4;
-          const bool ok = pf_live[j] && n < a.N;
-          pf_gate[i][j] = ok ? *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-          pf_x[i][j] = ok ? *(const f32x4*)(a.resid + (size_t)m * a.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-  }
-
   // NSTAGE-deep LDS ring fed by LDS-DMA: NSTAGE-1 K-tiles are in flight while one is consumed.  Counted vmcnt +
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
@@ -168,20 +159,90 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < KT) stage(s, s);
+  // Epilogue operands are fetched right after the first stages were issued and stay in flight under the first
+  // NSTAGE - 1 K-steps: vmcnt retires in order, so the waits for tiles 0 .. NSTAGE-2 (older than these loads) allow
+  // NPC more outstanding operations.  NPC counts only loads that are certainly issued: unconditional (clamped
+  // addresses), one 16-/8-byte vector load each, pinned between two asm memory barriers.  Over-counting would let a
+  // tile be read before it landed, so loads that may be skipped (bias, seq_len) are not counted (that only makes a wait
+  // conservative) and tools/check_vmcnt.py verifies on the compiled ISA that every instantiation issues >= NPC plain
+  // vector loads between the prologue's LDS-DMAs and the first counted wait (run by `make check`).  `volatile` is no
+  // way to pin them: hipcc turns volatile loads into flat_load sc0 sc1 + s_waitcnt vmcnt(0) each.
+  asm volatile("" ::: "memory");
+  constexpr bool PREF = (TM * TN <= 4);
+  static_assert(FUSE == 0 || (PREF && BM == 64 && BN == 64 && WGM == 2 && WGN == 2), "fused AdaLN: 64x64 tiles only");
+  static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
+  constexpr int NPC = FUSE == 1 ? 2 * TM * TN + 8 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0));
+  static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
+  f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
+  f32x4 pf_c[FUSE == 1 ? TN : 1][FUSE == 1 ? TM : 1], pf_d[FUSE == 1 ? TN : 1][FUSE == 1 ? TM : 1];
+  f32x4 pf_ns[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
+  f32x2 pf_st[FUSE == 1 ? 8 : 1];
+  bool pf_live[PREF ? TM : 1];
+  int pf_len[PREF ? TM : 1];
+  auto ldv4 = [](const float* ptr) -> f32x4 { return *(const f32x4*)ptr; };
+  if (PREF) {
+    if (EPI == EPI_GATE_RES) {
+      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm0 + j * 16 + fr, mc = min(m, a.M - 1);
+        const int seq = mc / a.rows_per_seq;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
+          const size_t goff = eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + nc;
+          pf_gate[i][j] = ldv4(a.gate + goff);                       // counted
+          pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);      // counted
+          if (FUSE == 2) pf_ns[i][j] = ldv4(a.next_scale + goff);    // counted
+        }
+      }
+    }
+  }
+  if (FUSE == 1) {
+    const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
+      const size_t roff = eoff + (size_t)((mc / a.rows_per_seq) % a.cd_rows) * a.cd_stride;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
+        pf_c[i][j] = ldv4(a.ln_c + roff + nc);                       // counted
+        pf_d[i][j] = ldv4(a.ln_d + roff + nc);                       // counted
+      }
+    }
+    // row statistics: 4 threads per row of the tile, each takes every 4th 64-column partial (<= 32 partials)
+    const int srow = min(m0 + (tid >> 2), a.M - 1), sq = tid & 3;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int part = min(sq + 4 * u, a.ln_parts - 1);
+      pf_st[u] = *(const f32x2*)(a.ln_stats + ((size_t)srow * a.ln_parts + part) * 2);  // counted
+    }
+  }
+  if (PREF) {  // not counted: may be skipped
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn0 + i * 16 + fq * 4;
+      pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (EPI == EPI_GATE_RES) {  // only fetched here; compared in the epilogue (a use now would drain vmcnt)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
+        pf_len[j] = a.seq_len ? a.seq_len[mc / a.rows_per_seq] : a.rows_per_seq;
+      }
+    }
+  }
+
   int buf = 0, nbuf = NSTAGE - 1;
   if constexpr (DBG == 3) { if (tid == 0) trc[2] = __builtin_amdgcn_s_memtime(); }
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = KT - 1 - kt;  // stages issued after tile kt
-    // tile kt must have landed; the min(NSTAGE - 2, rem) younger stages may stay in flight
-    switch (rem < NSTAGE - 2 ? rem : NSTAGE - 2) {
-      case 0: wait_vm_lgkm0<0>(); break;
-      case 1: wait_vm_lgkm0<LPT>(); break;
-      case 2: wait_vm_lgkm0<2 * LPT>(); break;
-      case 3: wait_vm_lgkm0<3 * LPT>(); break;
-      case 4: wait_vm_lgkm0<4 * LPT>(); break;
-      case 5: wait_vm_lgkm0<5 * LPT>(); break;
-      default: wait_vm_lgkm0<6 * LPT>(); break;
-    }
+    // tile kt must have landed; the min(NSTAGE - 2, rem) younger stages may stay in flight, and so may the NPC
+    // counted epilogue loads while tile kt is one of the prologue's
+    const int nst = rem < NSTAGE - 2 ? rem : NSTAGE - 2;
+    if (NPC > 0 && kt <= NSTAGE - 2) wait_stages<LPT, NPC>(nst);
+    else wait_stages<LPT, 0>(nst);
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
     if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
     if (DBG != 2 && kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
@@ -212,11 +273,57 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
 
   if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
+  float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // 1 KiB behind the ring (FUSE != 0 launches only)
+  if (FUSE == 1) {
+    // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
+    // M2 = sum_p M2_p + 64 sum_p (mean_p - mean)^2, rstd = rsqrt(M2 / K + eps)
+    const int sq = tid & 3;
+    float sm = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (sq + 4 * u < a.ln_parts) sm += pf_st[u][0];
+    sm += __shfl_xor(sm, 1, 64);
+    sm += __shfl_xor(sm, 2, 64);
+    const float mean = sm / (float)a.ln_parts;
+    const float cols = (float)(a.K / a.ln_parts);
+    float m2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (sq + 4 * u < a.ln_parts) {
+        const float dm = pf_st[u][0] - mean;
+        m2 += pf_st[u][1] + cols * dm * dm;
+      }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    if (sq == 0) {
+      fuse_lds[(tid >> 2) * 2] = mean;
+      fuse_lds[(tid >> 2) * 2 + 1] = rsqrtf(m2 / (float)a.K + a.ln_eps);
+    }
+    __syncthreads();
+  }
+  f32x4 xn[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
+  if (PREF && EPI == EPI_GATE_RES) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm0 + j * 16 + fr;
+      pf_live[j] = (m < a.M) && (m % a.rows_per_seq < pf_len[j]);
+    }
+  }
+
   // ---- epilogue: acc[i][j][r] = C[m = m0+wm0+16j+fr][n = n0+wn0+16i+4fq+r] ----
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm0 + j * 16 + fr;
+    if (FUSE == 2) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) xn[i][j] = pf_x[i][j];  // rows past M hold zeros (never stored)
+    }
     if (m >= a.M) continue;
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if (FUSE == 1) {
+      ln_mean = fuse_lds[(wm0 + j * 16 + fr) * 2];
+      ln_rstd = fuse_lds[(wm0 + j * 16 + fr) * 2 + 1];
+    }
     int seq = 0, pos = m;
     if (EPI == EPI_GATE_RES || EPI == EPI_QKV_ROPE) {
       seq = m / a.rows_per_seq;
@@ -247,7 +354,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       const int n = n0 + wn0 + i * 16 + fq * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
-      if (PREF) {
+      if (FUSE == 1) {
+        v = ln_rstd * (v - ln_mean * pf_c[i][j]) + pf_d[i][j];  // d carries the bias
+      } else if (PREF) {
         v += pf_bias[i];
       } else if (a.bias) {
         const f32x4 b = *(const f32x4*)(a.bias + n);
@@ -261,11 +370,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       } else if (EPI == EPI_F32) {
         *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
       } else if (EPI == EPI_GATE_RES && PREF) {
-        if (pf_live[j]) *(f32x4*)(a.resid + (size_t)m * a.ldr + n) = pf_x[i][j] + pf_gate[i][j] * v;
+        if (pf_live[j]) {  // pf_x / pf_gate were fetched from clamped addresses: valid whenever m < M and n < N
+          const f32x4 x_new = pf_x[i][j] + pf_gate[i][j] * v;
+          *(f32x4*)(a.resid + (size_t)m * a.ldr + n) = x_new;
+          if (FUSE == 2) xn[i][j] = x_new;
+        }
+        if (FUSE == 2) {
+          const f32x4 y = xn[i][j] * (1.0f + pf_ns[i][j]);
+          *(bf16x4*)(a.xs_out + (size_t)m * a.ld_xs + n) = f2bf4(y[0], y[1], y[2], y[3]);
+        }
       } else if (EPI == EPI_GATE_RES) {
         const bool live = (a.seq_len == nullptr) || (pos < a.seq_len[seq]);
         if (live) {
-          const size_t eoff = a.eval_ptr ? (size_t)(*a.eval_ptr) * a.eval_stride : 0;
+          const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
           const f32x4 g = *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n);
           float* xp = a.resid + (size_t)m * a.ldr + n;
           f32x4 x = *(const f32x4*)xp;
@@ -306,26 +423,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       }
     }
   }
+  if (FUSE == 2) {
+    // (mean, M2) of x_new over this wave's 32 columns, then the two waves of a row pair up through LDS
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) sm += (xn[i][j][0] + xn[i][j][1]) + (xn[i][j][2] + xn[i][j][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mw = sm * (1.0f / (float)WN);
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const f32x4 dv = xn[i][j] - mw;
+        q2 += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+      }
+      q2 += __shfl_xor(q2, 16, 64);
+      q2 += __shfl_xor(q2, 32, 64);
+      if (fq == 0) {
+        float* slot = fuse_lds + ((wm0 + j * 16 + fr) * WGN + (wave % WGN)) * 2;
+        slot[0] = mw;
+        slot[1] = q2;
+      }
+    }
+    // LDS hand-off only: do not drain vmcnt here, the x / xs stores above stay in flight behind the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < BM && m0 + tid < a.M) {
+      const float ma = fuse_lds[tid * 4], qa = fuse_lds[tid * 4 + 1], mb = fuse_lds[tid * 4 + 2], qb = fuse_lds[tid * 4 + 3];
+      const float dm = ma - mb;
+      float* dst = a.stats_out + ((size_t)(m0 + tid) * a.tiles_n + tile_n) * 2;
+      dst[0] = 0.5f * (ma + mb);
+      dst[1] = (qa + qb) + (0.25f * (float)BN) * dm * dm;  // delta^2 na nb / (na + nb), na = nb = BN / 2
+    }
+  }
   if constexpr (DBG == 3) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) { trc[40] = __builtin_amdgcn_s_memtime(); trc[41] = __builtin_amdgcn_s_memrealtime(); }
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.m_major = a.M > a.N;
   const int grid = a.tiles_m * a.tiles_n;
-  constexpr int lds = NSTAGE * (BM + BN) * 64 * 2;
+  constexpr int lds = NSTAGE * (BM + BN) * 64 * 2 + (FUSE ? 1024 : 0);
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
   if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -346,6 +498,18 @@ template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int sel = tile_hint % 10, ns = tile_hint / 10;
+  if (a.ln_stats || a.stats_out) {  // fused AdaLN: 64x64 tiles, ring depth by the same rule as below
+    F5E_REQUIRE(!(a.ln_stats && a.stats_out), "gemm_bf16: a launch is an AdaLN consumer or a producer, not both");
+    F5E_REQUIRE(!(EPI == EPI_QKV_ROPE && a.qn_w), "gemm_bf16: fused AdaLN and qk_norm need different tiles");
+    if constexpr (EPI == EPI_GATE_RES) {
+      F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
+      if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
+      return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
+    } else {
+      F5E_REQUIRE(a.ln_stats && !a.stats_out, "gemm_bf16: this epilogue can only consume AdaLN statistics");
+      return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
+    }
+  }
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
@@ -396,16 +560,35 @@ int check_common(const GemmArgs& a) {
   return F5E_OK;
 }
 
+int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
+  if (!ln || !ln->stats) return F5E_OK;
+  F5E_REQUIRE(bias == nullptr, "gemm_bf16: with fused AdaLN the bias is part of the d table");
+  F5E_REQUIRE(ln->c && ln->d && ln->parts > 0 && ln->parts <= 32 && a.K % ln->parts == 0 && ln->cd_rows > 0 &&
+                  ln->cd_stride % 4 == 0 && ln->cd_eval_stride % 4 == 0 && ln->rows_per_seq > 0,
+              "gemm_bf16: bad fused-AdaLN consumer arguments (parts=%d)", ln->parts);
+  a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;
+  a.cd_rows = ln->cd_rows; a.cd_eval_stride = ln->cd_eval_stride; a.ln_eps = ln->eps;
+  a.eval_ptr = ln->eval_ptr;
+  if (a.rows_per_seq <= 0) a.rows_per_seq = ln->rows_per_seq;
+  return F5E_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int f5e_gemm_bf16_bias(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                        int ldo, int M, int N, int K, int act, int out_f32, int tile_hint) {
+  return f5e_gemm_bf16_bias_ln(st, A, lda, W, ldw, bias, out, ldo, M, N, K, act, out_f32, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_bias_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                          int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln) {
   GemmArgs a{};
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
   if (int e = check_common(a)) return e;
+  if (int e = set_consumer(a, ln, bias)) return e;
   F5E_REQUIRE(out && ldo % 4 == 0, "gemm_bf16_bias: bad output");
   if (out_f32) {
     F5E_REQUIRE(act == F5E_ACT_NONE, "gemm_bf16_bias: f32 output supports no activation");
@@ -420,6 +603,14 @@ int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const vo
                                 float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
                                 const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
                                 int N, int K, int tile_hint) {
+  return f5e_gemm_bf16_gate_residual_ln(st, A, lda, W, ldw, bias, resid, ldr, gate, gate_stride, gate_rows, eval_ptr,
+                                        eval_stride, rows_per_seq, seq_len, M, N, K, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_gate_residual_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                   float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                   const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                   int N, int K, int tile_hint, const f5e_ln_fuse* ln) {
   GemmArgs a{};
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
@@ -428,6 +619,11 @@ int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const vo
   if (int e = check_common(a)) return e;
   F5E_REQUIRE(resid && gate && ldr % 4 == 0 && gate_stride % 4 == 0 && gate_rows > 0 && rows_per_seq > 0,
               "gemm_bf16_gate_residual: bad residual/gate arguments");
+  if (ln && ln->stats_out) {
+    F5E_REQUIRE(ln->xs_out && ln->next_scale && ln->ld_xs % 4 == 0 && N % 64 == 0,
+                "gemm_bf16_gate_residual: AdaLN producer needs xs_out, next_scale and N %% 64 == 0");
+    a.xs_out = (bf16*)ln->xs_out; a.ld_xs = ln->ld_xs; a.next_scale = ln->next_scale; a.stats_out = ln->stats_out;
+  }
   return dispatch<EPI_GATE_RES>(a, st, tile_hint);
 }
 
@@ -435,6 +631,14 @@ int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W
                            void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
                            const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
                            int tile_hint) {
+  return f5e_gemm_bf16_qkv_rope_ln(st, A, lda, W, ldw, bias, q, k, vt, n_pad, heads, rope_heads, cos_sin, q_norm_w,
+                                   k_norm_w, rows_per_seq, M, K, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_qkv_rope_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                              void* q, void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                              const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                              int tile_hint, const f5e_ln_fuse* ln) {
   GemmArgs a{};
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = 3 * heads * 64; a.K = K;
@@ -447,6 +651,7 @@ int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W
   F5E_REQUIRE(heads > 0 && rope_heads >= 0 && rope_heads <= heads, "gemm_bf16_qkv_rope: bad head counts");
   F5E_REQUIRE(rows_per_seq > 0 && n_pad >= rows_per_seq && n_pad % 64 == 0,
               "gemm_bf16_qkv_rope: n_pad=%d must be a multiple of 64 and >= rows_per_seq=%d", n_pad, rows_per_seq);
+  if (int e = set_consumer(a, ln, bias)) return e;
   return dispatch<EPI_QKV_ROPE>(a, st, tile_hint);
 }
 

@@ -119,6 +119,142 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Gemm32Args a) {
   }
 }
 
+// ---- LDS-DMA variant for K % 64 == 0 and no A-side activation (TextEmbedding / Vocos pointwise convs, head) ----
+// Same ring as gemm_bf16.hip: global_load_lds_dwordx4 into an NSTAGE-deep LDS ring, counted vmcnt + one raw
+// s_barrier per K-step of 64 floats (256-byte rows, 16 chunks of 16 B; chunk ^ (row & 15) on the source address and
+// on the ds_read_b128 -> each 16-lane group covers all 64 banks once).  A lane (fr, fq) reads 4 consecutive k of its
+// row and feeds them to 4 MFMAs; both operands use the same k permutation, so every k is visited exactly once.
+// The simple kernel above takes ~1.4 us per 16-wide K step (exposed global latency + 2 barriers): 45 us for
+// 281 x 1536 x 512; this one ~8 us.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
+  constexpr int BK = 64, NT = 256, ROWB = BK * 4;
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  constexpr int A_IT = BM * 16 / NT, W_IT = BN * 16 / NT, LPT = A_IT + W_IT;
+  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1 && A_IT >= 1 && W_IT >= 1, "tile / wave layout");
+  static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_n = blockIdx.x / a.tiles_m, tile_m = blockIdx.x - tile_n * a.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const float* a_src[A_IT];
+  const float* w_src[W_IT];
+#pragma unroll
+  for (int j = 0; j < A_IT; ++j) {
+    const int i = tid + NT * j, row = i >> 4, c = (i & 15) ^ (row & 15);
+    a_src[j] = a.A + (size_t)(min(m0 + row, a.M - 1) % a.a_rows) * a.lda + c * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < W_IT; ++j) {
+    const int i = tid + NT * j, row = i >> 4, c = (i & 15) ^ (row & 15);
+    w_src[j] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + c * 4;
+  }
+  auto dma = [](const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  };
+  auto stage = [&](int buf, int kt) {
+    char* base = smem32 + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) dma(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
+#pragma unroll
+    for (int j = 0; j < W_IT; ++j) dma(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
+  };
+
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = a.K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < KT) stage(s, s);
+  int buf = 0, nbuf = NSTAGE - 1;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int rem = KT - 1 - kt;
+    switch (rem < NSTAGE - 2 ? rem : NSTAGE - 2) {  // tile kt landed; that many younger stages may stay in flight
+      case 0: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(0) : "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
+    const char* As = smem32 + buf * STAGE;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 xf[TM], wf[TN];
+      const int c = g * 4 + fq;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm0 + j * 16 + fr;
+        xf[j] = *(const f32x4*)(As + row * ROWB + ((c ^ (row & 15)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn0 + i * 16 + fr;
+        wf[i] = *(const f32x4*)(Ws + row * ROWB + ((c ^ (row & 15)) << 4));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
+    }
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+  }
+
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm0 + j * 16 + fr;
+    if (m >= a.M) continue;
+    const float rs = a.row_scale ? a.row_scale[m] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn0 + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n + r;
+        if (nn >= a.N) continue;
+        float v = acc[i][j][r];
+        if (a.bias) v += a.bias[nn];
+        v = apply_act(v, a.act);
+        if (a.ch_scale) v *= a.ch_scale[nn];
+        if (a.addend) v += a.addend[(size_t)(m % a.add_rows) * a.ld_add + nn];
+        v *= rs;
+        if (a.out) a.out[(size_t)m * a.ldo + nn] = v;
+        if (a.out_bf16) a.out_bf16[(size_t)m * a.ldo_bf16 + nn] = (bf16)v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+int launch_dma(Gemm32Args& a, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  const int grid = a.tiles_m * ((a.N + BN - 1) / BN);
+  constexpr int lds = NSTAGE * (BM + BN) * 256;
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
+  if (lds > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), dim3(grid), dim3(256), lds, st, a);
+  F5E_LAUNCH_CHECK("gemm_f32_dma");
+  return F5E_OK;
+}
+
 }  // namespace
 
 extern "C" int f5e_gemm_f32(hipStream_t st, const float* A, int lda, int a_rows, int a_act, const float* W, int ldw,
@@ -135,6 +271,11 @@ extern "C" int f5e_gemm_f32(hipStream_t st, const float* A, int lda, int a_rows,
   a.ch_scale = ch_scale; a.addend = addend; a.ld_add = ld_add; a.add_rows = add_rows > 0 ? add_rows : 1;
   a.row_scale = row_scale; a.out = out; a.ldo = ldo; a.out_bf16 = (bf16*)out_bf16; a.ldo_bf16 = ldo_bf16;
   a.M = M; a.N = N; a.K = K;
+  if (K % 64 == 0 && a_act == F5E_ACT_NONE && (((uintptr_t)A | (uintptr_t)W) & 15) == 0) {
+    // few tiles: halve BM so more CUs take part (these GEMMs have M of a few hundred rows)
+    if (((M + 63) / 64) * ((N + 63) / 64) < 128) return launch_dma<32, 64, 2, 2, 4>(a, st);
+    return launch_dma<64, 64, 2, 2, 3>(a, st);
+  }
   a.tiles_m = (M + 63) / 64;
   const int grid = a.tiles_m * ((N + 63) / 64);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(grid), dim3(256), 0, st, a);

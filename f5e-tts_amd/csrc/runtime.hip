@@ -161,6 +161,47 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     HIP_TRY(hipMemcpyAsync(p->skip_res, p->x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st),
             "hipMemcpyAsync(skip_res)");
   }
+  if (p->fuse_ln) {
+    // Fused AdaLN chain (f5e_ln_fuse): hn holds xs = bf16(x (1 + scale)) for the next linear, ln_stats the tile
+    // statistics of x; every gate+residual GEMM refreshes both for the norm that follows it.
+    F5E_REQUIRE(!p->w_skip, "dit_forward: fused AdaLN does not cover the long skip connection");
+    F5E_REQUIRE(p->ln_stats && p->cd && D % 64 == 0 && D / 64 <= 32 && inner == D && p->cd_stride % 4 == 0,
+                "dit_forward: fused AdaLN needs ln_stats, cd tables, D %% 64 == 0, D <= 2048 and heads * 64 == D");
+    const int parts = D / 64, ls = 6 * inner + 2 * p->FF, cd_eval_stride = p->mod_rows * p->cd_stride;
+    F5E_REQUIRE(p->cd_stride >= p->L * ls + 2 * p->mel, "dit_forward: cd_stride too small");
+    f5e_ln_fuse cons{}, prod{};
+    cons.stats = p->ln_stats; cons.parts = parts; cons.cd_stride = p->cd_stride; cons.cd_rows = p->mod_rows;
+    cons.cd_eval_stride = cd_eval_stride; cons.eval_ptr = p->eval_ptr; cons.rows_per_seq = p->N; cons.eps = 1e-6f;
+    prod.xs_out = p->hn; prod.ld_xs = D; prod.stats_out = p->ln_stats;
+    F5E_TIMED(F5E_OP_LN, f5e_adaln_pre(st, p->x, D, p->hn, D, p->mod + D, row_stride, p->mod_rows, p->N, p->eval_ptr,
+                                       eval_stride, p->ln_stats, parts, M, D));
+    for (int l = 0; l < p->L; ++l) {
+      const f5e_dit_block_weights& w = p->blocks[l];
+      F5E_REQUIRE(!w.q_norm_w, "dit_forward: fused AdaLN and qk_norm are exclusive");
+      const float* mb = p->mod + (size_t)l * 6 * D;
+      const float* cdl = p->cd + (size_t)l * ls;
+      cons.c = cdl; cons.d = cdl + 3 * inner;
+      F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_ln(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
+                                        p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons));
+      F5E_TIMED(F5E_OP_ATTN, f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
+      prod.next_scale = mb + 4 * D;  // scale_mlp
+      F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual_ln(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D,
+                                          row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D,
+                                          inner, 0, &prod));
+      cons.c = cdl + 6 * inner; cons.d = cdl + 6 * inner + p->FF;
+      F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_ln(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
+                                    F5E_ACT_GELU_TANH, 0, 0, &cons));
+      // next norm: attn_norm of block l+1 (scale_msa at +D) or the final AdaLN (scale first: modules.py:333)
+      prod.next_scale = (l + 1 < p->L) ? mb + 6 * D + D : p->mod + (size_t)p->L * 6 * D;
+      F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_ln(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,
+                                          row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF,
+                                          0, &prod));
+    }
+    cons.c = p->cd + (size_t)p->L * ls; cons.d = cons.c + p->mel;
+    F5E_TIMED(F5E_OP_FINAL, f5e_gemm_bf16_bias_ln(st, p->hn, D, p->w_proj, D, nullptr, p->pred, p->mel, M, p->mel, D,
+                                    F5E_ACT_NONE, 1, 0, &cons));
+    return F5E_OK;
+  }
   for (int l = 0; l < p->L; ++l) {
     const f5e_dit_block_weights& w = p->blocks[l];
     const float* mb = p->mod + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp

@@ -14,6 +14,7 @@ CFM.sample / sample_tts / sample_vc (model/cfm.py:430-471), restructured for MI3
 from __future__ import annotations
 
 import math
+import os
 import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -136,6 +137,8 @@ class DiTEngine:
         inv = sd.get("rotary_embed.inv_freq")
         self.inv_freq = (inv.detach().float() if inv is not None
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
+        # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
+        self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
         self._graphs: Dict[tuple, "_LoopGraph"] = {}
         self._tables: Dict[tuple, Tensor] = {}
         self._lock = threading.Lock()
@@ -169,14 +172,53 @@ class DiTEngine:
 
     # ------------------------------------------------------------------ once-per-call pieces
 
-    def time_tables_cached(self, t_host: Tensor) -> Tensor:
-        """Tables depend on the time grid only, so calls that share (steps, sway, solver) share them.  The cache is
-        keyed by the exact grid values and is read-only once built (safe to share between threads)."""
+    # Above this many rows per launch the 128x128 GEMM tiles win and LayerNorm is HBM-bound anyway: keep it separate.
+    LN_FUSE_MAX_ROWS = 4096
+
+    @property
+    def can_fuse_ln(self) -> bool:
+        cfg = self.cfg
+        return (cfg.qk_norm is None and not cfg.long_skip_connection and cfg.dim % 64 == 0 and cfg.dim <= 2048
+                and self.inner == cfg.dim)
+
+    def cd_tables(self, mod: Tensor) -> Tensor:
+        """Tables of the fused AdaLN (f5e_ln_fuse): for every evaluation row of `mod` and every linear that follows a
+        modulated LayerNorm,  c[n] = sum_k W[n][k] (1 + scale[k])  and  d[n] = sum_k W[n][k] shift[k] + bias[n],  with
+        W the bf16 weights the MFMA kernels use.  Layout per row: L x (c_qkv | d_qkv | c_ff1 | d_ff1), c_proj | d_proj."""
+        cfg, dv = self.cfg, self.device
+        D, L, FF, inner, mel = cfg.dim, self.L, self.FF, self.inner, cfg.mel_dim
+        E, rows, _ = mod.shape
+        m2 = mod.view(E * rows, self.row_stride)
+        ls = 6 * inner + 2 * FF
+        stride = (L * ls + 2 * mel + 3) // 4 * 4
+        cd = torch.zeros(E * rows, stride, device=dv)
+        one_plus = torch.empty(E * rows, D, device=dv)
+
+        def pair(scale, shift, w_bf, bias, off, n):
+            w = w_bf.float()
+            torch.add(scale, 1.0, out=one_plus)
+            ops.gemm_f32(one_plus, w, None, out=cd[:, off:off + n])
+            ops.gemm_f32(shift, w, bias, out=cd[:, off + n:off + 2 * n])
+
+        for l in range(L):
+            w_qkv, b_qkv, _, _, w_ff1, b_ff1 = self.blocks_keep[l][:6]
+            mb = m2[:, l * 6 * D:(l + 1) * 6 * D]
+            pair(mb[:, D:2 * D], mb[:, :D], w_qkv, b_qkv, l * ls, 3 * inner)
+            pair(mb[:, 4 * D:5 * D], mb[:, 3 * D:4 * D], w_ff1, b_ff1, l * ls + 6 * inner, FF)
+        mf = m2[:, L * 6 * D:]
+        pair(mf[:, :D], mf[:, D:2 * D], self.proj_w, self.proj_b, L * ls, mel)
+        return cd.view(E, rows, stride)
+
+    def time_tables_cached(self, t_host: Tensor):
+        """(mod, cd) tables: they depend on the time grid only, so calls that share (steps, sway, solver) share them.
+        The cache is keyed by the exact grid values and is read-only once built (safe to share between threads).
+        cd is None when the architecture rules the fused AdaLN out."""
         key = tuple(t_host.tolist())
         with self._lock:
             hit = self._tables.get(key)
         if hit is None:
-            hit = self.time_tables(h2d(t_host, self.device))
+            mod = self.time_tables(h2d(t_host, self.device))
+            hit = (mod, self.cd_tables(mod) if self.can_fuse_ln else None)
             with self._lock:
                 if len(self._tables) >= 8:
                     self._tables.pop(next(iter(self._tables)))
@@ -291,7 +333,8 @@ class DiTEngine:
     # ------------------------------------------------------------------ plan / workspace
 
     def make_plan(self, S: int, B: int, N: int, y: Tensor, in_const: Tensor, mod: Tensor, eval_ptr: Optional[Tensor],
-                  rope_cs: Tensor, seq_len: Optional[Tensor], pred: Optional[Tensor] = None) -> "_Plan":
+                  rope_cs: Tensor, seq_len: Optional[Tensor], pred: Optional[Tensor] = None,
+                  cd: Optional[Tensor] = None) -> "_Plan":
         cfg, dv = self.cfg, self.device
         D, H, mel = cfg.dim, cfg.heads, cfg.mel_dim
         n_pad = (N + 63) // 64 * 64
@@ -324,7 +367,10 @@ class DiTEngine:
             p.w_skip = self.skip_w.data_ptr()
         for k, t in ws.items():
             setattr(p, k, t.data_ptr())
-        return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len))
+        if cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS:
+            ws["ln_stats"] = torch.empty(M, D // 64, 2, device=dv)
+            p.fuse_ln, p.ln_stats, p.cd, p.cd_stride = 1, ws["ln_stats"].data_ptr(), cd.data_ptr(), cd.shape[2]
+        return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len, cd))
 
     def forward(self, plan: "_Plan") -> Tensor:
         ops.dit_forward(plan.c)
@@ -424,7 +470,9 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     E = steps * eps_per_step
 
     # once-per-call tensors
-    mod = engine.time_tables_cached(t_eval)                       # [E, 1, row_stride]
+    mod, cd = engine.time_tables_cached(t_eval)                   # [E, 1, row_stride], [E, 1, cd_stride] or None
+    if not engine.fuse_ln:
+        cd = None
     in_const = torch.empty(S * N, cfg.dim, device=dv)
     cache: Dict[tuple, Tensor] = {}
     for bi, (da, dt_, dp) in enumerate(inp.branches):
@@ -468,7 +516,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             lo, hi = c * per * B * N, (c + 1) * per * B * N
             sl = seq_len[c * per * B:(c + 1) * per * B].contiguous() if seq_len is not None else None
             out.append(engine.make_plan(per * B, B, N, y_in, in_const[lo:hi], mod, eval_ptr, rope_cs, sl,
-                                        pred=pred_all[lo:hi]))
+                                        pred=pred_all[lo:hi], cd=cd))
         return out
 
     plans_a = plans_for(y)
@@ -511,6 +559,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
 
     if use_graph and steps > 1:
+        ops.Graph.reap()
         gr = ops.Graph()
         gr.begin()
         try:
@@ -521,6 +570,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             gr.launch()
             if want_trajectory:
                 traj[i + 1].copy_(y)
+        gr.retire()   # the launches are still queued: destroy the executable graph only once they have run
     else:
         for i in range(steps):
             one_step(traj[i + 1] if want_trajectory else None)

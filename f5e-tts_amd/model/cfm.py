@@ -111,8 +111,13 @@ class CFM(nn.Module):
         y0 = torch.zeros(batch, n, self.num_channels, dtype=F32)
         for i, dur in enumerate(dur_h.tolist()):
             if exists(seed):
-                torch.manual_seed(seed)
-            y0[i, :dur] = torch.randn(dur, self.num_channels, dtype=F32)
+                # same stream as the reference's `torch.manual_seed(seed); torch.randn(...)` on the default CPU generator,
+                # but private to this call: callers sample from several threads on one model (utils_infer.py:511) and
+                # the seed + draw pair on the global generator is not atomic
+                gen = torch.Generator().manual_seed(seed)
+                y0[i, :dur] = torch.randn(dur, self.num_channels, dtype=F32, generator=gen)
+            else:
+                y0[i, :dur] = torch.randn(dur, self.num_channels, dtype=F32)
         y0 = h2d(y0, dv)
         t_start = 0
         if duplicate_test:

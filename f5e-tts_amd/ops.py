@@ -3,6 +3,7 @@ device memory and the stream; every computation happens in libf5e_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -44,42 +45,83 @@ def _p(t: Optional[Tensor], dtype=None, name="tensor"):
 BF, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 
 
-def gemm_bf16_bias(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, act: int = ACT_NONE, tile_hint: int = 0):
-    """out[M,N] = act(a[M,K] @ w[N,K].T + bias); out bf16 or f32 (no activation)."""
+def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, eval_ptr: Optional[Tensor] = None,
+                cd_eval_stride: int = 0, eps: float = 1e-6) -> "_C.LnFuse":
+    """Consumer side of the fused AdaLN (see f5e_ln_fuse): stats f32 [M, parts, 2]; c, d f32 [cd_rows, N] views."""
+    if c.stride(0) != d.stride(0) or c.shape != d.shape:
+        raise _C.F5EError("c and d tables must share shape and row stride")
+    f = _C.LnFuse()
+    f.stats, f.parts = _p(stats, F32, "stats").value, stats.shape[1]
+    f.c, f.d, f.cd_stride, f.cd_rows = c.data_ptr(), d.data_ptr(), c.stride(0), c.shape[0]
+    f.cd_eval_stride, f.rows_per_seq, f.eps = cd_eval_stride, rows_per_seq, eps
+    f.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
+    f._keep = (stats, c, d, eval_ptr)
+    return f
+
+
+def ln_producer(xs_out: Tensor, next_scale: Tensor, stats_out: Tensor) -> "_C.LnFuse":
+    """Producer side: xs_out bf16 [M, N]; next_scale f32 [gate_rows, N] view with the gate's row stride;
+    stats_out f32 [M, N // 64, 2]."""
+    f = _C.LnFuse()
+    f.xs_out, f.ld_xs = _p(xs_out, BF, "xs_out").value, xs_out.stride(0)
+    f.next_scale, f.stats_out = next_scale.data_ptr(), _p(stats_out, F32, "stats_out").value
+    f._keep = (xs_out, next_scale, stats_out)
+    return f
+
+
+def _ln_ref(ln):
+    return C.byref(ln) if ln is not None else None
+
+
+def adaln_pre(x: Tensor, xs: Tensor, scale: Tensor, stats: Tensor, rows_per_seq: int,
+              eval_ptr: Optional[Tensor] = None, eval_stride: int = 0):
+    """Head of the fused-AdaLN chain: xs = bf16(x (1 + scale[r])), stats[row] = `parts` equal shares of (mean, M2)."""
+    require_device()
+    rows, D = x.shape
+    check(lib().f5e_adaln_pre(_stream(), _p(x, F32, "x"), x.stride(0), _p(xs, BF, "xs"), xs.stride(0),
+                              C.c_void_p(scale.data_ptr()), scale.stride(0), scale.shape[0], rows_per_seq,
+                              _p(eval_ptr, I32, "eval_ptr"), eval_stride, _p(stats, F32, "stats"), stats.shape[1],
+                              rows, D), "f5e_adaln_pre")
+
+
+def gemm_bf16_bias(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, act: int = ACT_NONE, tile_hint: int = 0,
+                   ln=None):
+    """out[M,N] = act(a[M,K] @ w[N,K].T + bias); out bf16 or f32 (no activation).  ln: ``ln_consumer(...)``."""
     require_device()
     M, K = a.shape
     N = w.shape[0]
-    check(lib().f5e_gemm_bf16_bias(_stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0),
-                                   _p(bias, F32, "bias"), _p(out, None, "out"), out.stride(0), M, N, K, act,
-                                   1 if out.dtype == F32 else 0, tile_hint), "f5e_gemm_bf16_bias")
+    check(lib().f5e_gemm_bf16_bias_ln(_stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0),
+                                      _p(bias, F32, "bias"), _p(out, None, "out"), out.stride(0), M, N, K, act,
+                                      1 if out.dtype == F32 else 0, tile_hint, _ln_ref(ln)), "f5e_gemm_bf16_bias")
     return out
 
 
 def gemm_bf16_gate_residual(a: Tensor, w: Tensor, bias: Optional[Tensor], resid: Tensor, gate: Tensor,
                             rows_per_seq: int, seq_len: Optional[Tensor] = None, eval_ptr: Optional[Tensor] = None,
-                            eval_stride: int = 0, tile_hint: int = 0):
-    """resid[M,N] += gate[seq % rows] * (a @ w.T + bias), rows past seq_len skipped. gate: [rows, N] f32 view."""
+                            eval_stride: int = 0, tile_hint: int = 0, ln=None):
+    """resid[M,N] += gate[seq % rows] * (a @ w.T + bias), rows past seq_len skipped. gate: [rows, N] f32 view.
+    ln: ``ln_producer(...)`` to also emit the next fused-AdaLN consumer's inputs."""
     require_device()
     M, K = a.shape
     N = w.shape[0]
-    check(lib().f5e_gemm_bf16_gate_residual(
+    check(lib().f5e_gemm_bf16_gate_residual_ln(
         _stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0), _p(bias, F32, "bias"),
         _p(resid, F32, "resid"), resid.stride(0), C.c_void_p(gate.data_ptr()), gate.stride(0), gate.shape[0],
-        _p(eval_ptr, I32, "eval_ptr"), eval_stride, rows_per_seq, _p(seq_len, I32, "seq_len"), M, N, K, tile_hint),
-        "f5e_gemm_bf16_gate_residual")
+        _p(eval_ptr, I32, "eval_ptr"), eval_stride, rows_per_seq, _p(seq_len, I32, "seq_len"), M, N, K, tile_hint,
+        _ln_ref(ln)), "f5e_gemm_bf16_gate_residual")
     return resid
 
 
 def gemm_bf16_qkv_rope(a: Tensor, w: Tensor, bias: Tensor, q: Tensor, k: Tensor, vt: Tensor, heads: int,
                        rope_heads: int, cos_sin: Tensor, rows_per_seq: int, tile_hint: int = 0,
-                       q_norm_w: Optional[Tensor] = None, k_norm_w: Optional[Tensor] = None):
+                       q_norm_w: Optional[Tensor] = None, k_norm_w: Optional[Tensor] = None, ln=None):
     require_device()
     M, K = a.shape
     n_pad = q.shape[2]
-    check(lib().f5e_gemm_bf16_qkv_rope(
+    check(lib().f5e_gemm_bf16_qkv_rope_ln(
         _stream(), _p(a, BF, "a"), a.stride(0), _p(w, BF, "w"), w.stride(0), _p(bias, F32, "bias"), _p(q, BF, "q"),
         _p(k, BF, "k"), _p(vt, BF, "vt"), n_pad, heads, rope_heads, _p(cos_sin, F32, "cos_sin"),
-        _p(q_norm_w, F32, "q_norm_w"), _p(k_norm_w, F32, "k_norm_w"), rows_per_seq, M, K, tile_hint),
+        _p(q_norm_w, F32, "q_norm_w"), _p(k_norm_w, F32, "k_norm_w"), rows_per_seq, M, K, tile_hint, _ln_ref(ln)),
         "f5e_gemm_bf16_qkv_rope")
 
 
@@ -297,10 +339,36 @@ def dit_forward(plan: "_C.DitPlan"):
 
 
 class Graph:
-    """hipGraph captured through the C ABI on the current (non-default) torch stream."""
+    """hipGraph captured through the C ABI on the current (non-default) torch stream.
+
+    An executable graph owns the kernel-argument storage of its nodes, so it must outlive the launches that are still
+    queued: ``retire()`` parks it behind an event recorded on the launch stream and ``reap()`` destroys the parked
+    graphs whose event has completed (callers never block on the GPU for this)."""
+
+    _parked = []
+    _parked_lock = threading.Lock()
 
     def __init__(self):
         self.handle = C.c_void_p()
+
+    def retire(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with Graph._parked_lock:
+            Graph._parked.append((self, ev))
+
+    @staticmethod
+    def reap():
+        with Graph._parked_lock:
+            done = [x for x in Graph._parked if x[1].query()]
+            Graph._parked[:] = [x for x in Graph._parked if not x[1].query()]
+        for g, _ in done:
+            g.destroy()
+
+    def destroy(self):
+        if self.handle:
+            lib().f5e_graph_destroy(self.handle)
+            self.handle = C.c_void_p()
 
     def begin(self):
         require_device()
@@ -314,7 +382,6 @@ class Graph:
 
     def __del__(self):
         try:
-            if self.handle:
-                lib().f5e_graph_destroy(self.handle)
+            self.destroy()
         except Exception:
             pass

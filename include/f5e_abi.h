@@ -67,6 +67,34 @@ int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W,
                            const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
                            int tile_hint);
 
+/* Fused AdaLayerNorm for small row counts (batch-1 sampling): the LayerNorm + modulate launch in front of a linear
+ * (modules.py:308-314 + :452-454; :637 + :349; :329-335 + dit.py:470) is folded into the GEMMs either side of it.
+ *   producer = the gate+residual GEMM before it: next to x_new it writes xs = bf16(x_new (1 + next_scale[n])) and,
+ *     per row and 64-column tile, (mean, M2) of x_new into stats_out [M][N / 64][2];
+ *   consumer = the linear after it, run on A = xs:  out = rstd (acc - mean c[n]) + d[n]  with the per-evaluation
+ *     tables c[n] = sum_k W[n][k] (1 + scale[k]),  d[n] = sum_k W[n][k] shift[k] + bias[n]  (row r =
+ *     (m / rows_per_seq) % cd_rows, advanced by (*eval_ptr) * cd_eval_stride), mean / rstd combined from the
+ *     `parts` tile statistics (Chan's formula, fixed order); pass bias = NULL to the GEMM.
+ * Only one side is used per launch; leave the other side's pointers NULL.  64x64 tiles (the small-M tile). */
+typedef struct f5e_ln_fuse {
+  const float* stats; int parts;                       /* consumer */
+  const float* c; const float* d; int cd_stride; int cd_rows; int cd_eval_stride;
+  const int* eval_ptr; int rows_per_seq; float eps;
+  void* xs_out; int ld_xs; const float* next_scale;    /* producer (next_scale uses the gate's strides / rows) */
+  float* stats_out;
+} f5e_ln_fuse;
+
+int f5e_gemm_bf16_bias_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                          int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln);
+int f5e_gemm_bf16_gate_residual_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                   float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                   const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                   int N, int K, int tile_hint, const f5e_ln_fuse* ln);
+int f5e_gemm_bf16_qkv_rope_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                              void* q, void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                              const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                              int tile_hint, const f5e_ln_fuse* ln);
+
 /* ---------------------------------------------------------------- attention ---------------------------------- */
 
 /* o[S*rows_per_seq][ldo] (bf16, column = head*64 + d) = softmax(q k^T / 8 + keymask) v, keys >= kv_len[s] masked.
@@ -85,6 +113,12 @@ int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, 
 int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* gamma,
                   const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
                   int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps);
+
+/* First producer of the fused-AdaLN chain (block 0 has no GEMM in front of its norm): xs = bf16(x (1 + scale[r]))
+ * and stats [rows][parts][2] holding `parts` equal shares (mean, M2 / parts) of each row's statistics. */
+int f5e_adaln_pre(f5e_stream st, const float* x, int ldx, void* xs, int ld_xs, const float* scale, int mod_stride,
+                  int mod_rows, int rows_per_seq, const int* eval_ptr, int eval_stride, float* stats, int parts,
+                  int rows, int D);
 
 /* x_transformers.RMSNorm used by UNetT (backbones/unett.py:151,161,178): y = x / max(||x||_2, 1e-12) * sqrt(D) * g. */
 int f5e_l2norm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D);
@@ -194,6 +228,11 @@ typedef struct f5e_dit_plan {
   /* optional instrumentation (eager launches only, never inside graph capture) */
   void* timer;                           /* from f5e_timer_create, or NULL */
   int timer_op;                          /* F5E_OP_* op class to bracket with HIP events */
+  /* fused AdaLN (f5e_ln_fuse): 2 L + 1 LayerNorm launches become one f5e_adaln_pre.  Needs no long skip / qk_norm. */
+  int fuse_ln;                           /* 0 = separate LayerNorm launches */
+  float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
+  const float* cd;                       /* [E][mod_rows][cd_stride] f32: per block c_qkv | d_qkv | c_ff1 | d_ff1 */
+  int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
 } f5e_dit_plan;
 
 enum { F5E_OP_NONE = 0, F5E_OP_INPROJ = 1, F5E_OP_CONVPOS = 2, F5E_OP_LN = 3, F5E_OP_QKV = 4, F5E_OP_ATTN = 5,

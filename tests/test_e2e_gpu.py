@@ -119,6 +119,32 @@ def test_cfm_sample_c1_parity(graph):
     assert maxabs < 0.03 * rng
 
 
+def test_fused_adaln_matches_separate_layernorm():
+    """The sampler folds the AdaLN LayerNorms into the neighbouring GEMMs (f5e_ln_fuse).  Same algebra, different
+    rounding points: both paths must sit at the same distance from the fp32 oracle, masked batch included."""
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    g = torch.Generator().manual_seed(18)
+    cond = torch.randn(2, 40, 100, generator=g)
+    text = torch.randint(0, 300, (2, 12), generator=g)
+    kw = dict(duration=torch.tensor([90, 75]), lens=torch.tensor([40, 33]), steps=4, cfg_strength=2.0,
+              sway_sampling_coef=-1.0, seed=3)
+    ref_out, ref_traj = O.cfm_sample(sd, cfg, cond, text, None, **kw)
+    eng = dit.engine()
+    assert eng.can_fuse_ln and eng.fuse_ln
+    res = {}
+    for fuse in (True, False):
+        eng.fuse_ln = fuse
+        o, t = cfm.sample(cond.cuda(), text.cuda(), **kw)
+        res[fuse] = (t, rel_l2(t[-1], ref_traj[-1]))
+    eng.fuse_ln = True
+    print("rel L2 vs oracle: fused %.2e separate %.2e; fused vs separate %.2e"
+          % (res[True][1], res[False][1], rel_l2(res[True][0][-1], res[False][0][-1].cpu())))
+    assert res[True][1] < 1.5e-2 and res[False][1] < 1.5e-2
+    assert res[True][1] < 2.0 * res[False][1] + 1e-3
+    assert not torch.equal(res[True][0][-1], res[False][0][-1])      # the fused path really ran
+
+
 def test_graph_equals_eager_bitwise():
     cfg = O.DiTConfig(**SMALL)
     sd, dit, cfm = build(cfg)
@@ -313,8 +339,8 @@ def test_concurrent_sample_calls_from_two_threads():
         text = torch.randint(0, 300, (1, 9 + i), generator=g).cuda()
         jobs.append(dict(cond=cond, text=text, duration=n, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=20 + i))
     seq = [cfm.sample(**j)[0].clone() for j in jobs]
-    for _ in range(3):
-        with ThreadPoolExecutor(max_workers=2) as ex:
+    for workers in (2, 3, 2, 4, 2, 3):
+        with ThreadPoolExecutor(max_workers=workers) as ex:
             par = list(ex.map(lambda j: cfm.sample(**j)[0].clone(), jobs))
         torch.cuda.synchronize()
         for a, b in zip(seq, par):

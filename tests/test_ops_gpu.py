@@ -203,7 +203,8 @@ def test_grn(ops):
     close(out, O.grn(x, gam, bet), 1e-5, 1e-5, "grn")
 
 
-@pytest.mark.parametrize("M,N,K", [(100, 1024, 100), (469, 512, 1024), (33, 1026, 512), (5, 64, 4)])
+@pytest.mark.parametrize("M,N,K", [(100, 1024, 100), (469, 512, 1024), (33, 1026, 512), (5, 64, 4), (281, 1536, 512),
+                                   (938, 1024, 1536), (70, 100, 64)])
 def test_gemm_f32(ops, M, N, K):
     a = torch.randn(M, K + 12, generator=g(25))[:, :K]          # strided views on purpose (lda != K)
     w = torch.randn(N, K + 8, generator=g(26))[:, :K] / math.sqrt(K)
@@ -224,6 +225,12 @@ def test_gemm_f32(ops, M, N, K):
                  ch_scale=dev(cs), addend=dev(add), row_scale=dev(rs))
     close(out2, ref2, 1e-5, 3e-5, "full epilogue")
     close(out2b, ref2, 2 ** -7, 1e-3, "bf16 copy")
+    # the same epilogue without the A-side activation: K % 64 == 0 shapes take the LDS-DMA kernel here
+    ref3 = ((F.gelu(a @ w.T + b) * cs)[torch.arange(2 * M) % M] + add[torch.arange(2 * M) % M]) * rs[:, None]
+    ops.gemm_f32(ad, wd, dev(b), out=out2, out_bf16=out2b, M=2 * M, act=ops.ACT_GELU_ERF, ch_scale=dev(cs),
+                 addend=dev(add), row_scale=dev(rs))
+    close(out2, ref3, 1e-5, 3e-5, "full epilogue, plain A")
+    close(out2b, ref3, 2 ** -7, 1e-3, "bf16 copy, plain A")
     for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_MISH, F.mish), (ops.ACT_GELU_TANH, lambda t: F.gelu(t, approximate="tanh"))):
         ops.gemm_f32(ad, wd, dev(b), out=out, act=act)
         close(out, fn(ref), 1e-5, 3e-5, f"act {act}")
@@ -361,3 +368,64 @@ def test_qkv_rope_with_qk_rmsnorm(ops):
     close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q normed")
     close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k normed")
     close(unq(vt, vi)[:, :, :N], lin[2], 2 ** -7, 4e-3, "v untouched")
+
+
+@pytest.mark.parametrize("S,N,D,NO,mean_shift,masked", [(2, 469, 1024, 3072, 0.0, False), (2, 100, 768, 1536, 0.7, True),
+                                                          (1, 33, 1024, 100, 0.3, False)])
+def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked):
+    """LayerNorm+modulate folded into the GEMMs either side of it (f5e_ln_fuse): adaln_pre / the gate+residual producer
+    -> consumer linear, against LN(x)(1+scale)+shift -> linear in fp32 (reference modules.py:308-314 + :452-454,
+    :637 + :349) and against the unfused HIP ops."""
+    M, P = S * N, D // 64
+    x = torch.randn(M, D, generator=g(70)) * 1.5 + mean_shift
+    mod = torch.randn(1, 3 * D, generator=g(71)) * 0.3                      # scale | shift | gate
+    scale, shift, gate = mod[:, :D], mod[:, D:2 * D], mod[:, 2 * D:]
+    w = (torch.randn(NO, D, generator=g(72)) / math.sqrt(D)).to(BF)
+    b = torch.randn(NO, generator=g(73)) * 0.1
+    wf = w.float()
+    ref = (F.layer_norm(x, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
+    c = ((1 + scale) @ wf.T).contiguous()                                      # tables, one row (mod_rows = 1)
+    dd = (shift @ wf.T + b).contiguous()
+    xd, modd = dev(x), dev(mod)
+    xs = torch.empty(M, D, device="cuda", dtype=BF)
+    stats = torch.empty(M, P, 2, device="cuda")
+    ops.adaln_pre(xd, xs, modd[:, :D], stats, N)
+    close(xs, (x * (1 + scale)).to(BF), 0, 0, "pre xs")
+    close(stats[:, :, 0], x.mean(1, keepdim=True).expand(M, P), 1e-5, 1e-6, "pre mean")
+    close(stats[:, :, 1].sum(1), ((x - x.mean(1, keepdim=True)) ** 2).sum(1), 1e-5, 1e-4, "pre M2")
+    out = torch.empty(M, NO, device="cuda")
+    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N))
+    hn = torch.empty(M, D, device="cuda", dtype=BF)
+    ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:2 * D], rows_per_seq=N)
+    unf = torch.empty(M, NO, device="cuda")
+    ops.gemm_bf16_bias(hn, dev(w), dev(b), unf)
+    spread = float(ref.std())
+    e_f, e_u = float((out.cpu() - ref).abs().max()) / spread, float((unf.cpu() - ref).abs().max()) / spread
+    assert e_f < 3e-2 and e_f < 2.5 * e_u + 1e-3, (e_f, e_u)              # bf16-level, on par with the unfused path
+    assert float((out.cpu() - ref).pow(2).mean().sqrt()) / spread < 4e-3
+
+    # producer: gate + residual GEMM that also emits the next consumer's xs and tile statistics
+    K2 = 2 * D
+    a2 = (torch.randn(M, K2, generator=g(74))).to(BF)
+    w2 = (torch.randn(D, K2, generator=g(75)) / math.sqrt(K2)).to(BF)
+    b2 = torch.randn(D, generator=g(76)) * 0.1
+    seq_len = torch.tensor([N - 7, N][:S], dtype=torch.int32) if masked else None
+    x_plain, x_fused = xd.clone(), xd.clone()
+    ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2), x_plain, modd[:, 2 * D:], N,
+                                seq_len=dev(seq_len) if masked else None)
+    xs2 = torch.zeros(M, D, device="cuda", dtype=BF)
+    st2 = torch.zeros(M, P, 2, device="cuda")
+    ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2), x_fused, modd[:, 2 * D:], N,
+                                seq_len=dev(seq_len) if masked else None, ln=ops.ln_producer(xs2, modd[:, :D], st2))
+    assert torch.equal(x_plain, x_fused)                                    # the residual update itself is unchanged
+    xn = x_fused.cpu()
+    if masked:
+        assert torch.equal(xn[N - 7:N], x[N - 7:N])                         # masked rows keep x ...
+    close(xs2, (xn * (1 + scale)).to(BF), 0, 0, "producer xs")             # ... and still get xs and statistics
+    tiles = xn.view(M, P, 64)
+    close(st2[:, :, 0], tiles.mean(2), 1e-5, 1e-6, "producer tile mean")
+    close(st2[:, :, 1], ((tiles - tiles.mean(2, keepdim=True)) ** 2).sum(2), 1e-4, 1e-4, "producer tile M2")
+    out2 = torch.empty(M, NO, device="cuda")
+    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N))
+    ref2 = (F.layer_norm(xn, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
+    assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) / float(ref2.std()) < 4e-3

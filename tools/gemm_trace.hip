@@ -25,6 +25,10 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
     case 3: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3>(a, st);
     case 4: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 2, 2, 3>(a, st);
     case 5: *bm = 64; *bn = 64; return launch<64, 64, EPI, 2, 2, 2, 3>(a, st);
+    case 10:  // fused AdaLN: consumer for the bf16 / gelu epilogues, producer for gate + residual
+      *bm = 64; *bn = 64;
+      if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 3, 2, 2, 3, 2>(a, st);
+      else return launch<64, 64, EPI, 3, 2, 2, 3, 1>(a, st);
   }
   return -1;
 }
@@ -51,6 +55,11 @@ int main(int argc, char** argv) {
   hipMalloc(&gate, N * 4);
   hipMalloc(&resid, (size_t)M * N * 4);
   hipMalloc(&trace, (size_t)L * max_grid * 48 * 8);
+  float *stats, *cd;
+  hipMalloc(&stats, (size_t)M * 32 * 2 * 4);
+  hipMalloc(&cd, (size_t)2 * N * 4);
+  hipMemset(stats, 0, (size_t)M * 32 * 2 * 4);
+  hipMemset(cd, 0, (size_t)2 * N * 4);
   {  // small random-ish fill (values do not matter for timing, but keep them finite)
     std::vector<unsigned short> h((size_t)NW * N * K);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 25);  // ~[0.0078, 0.0156]
@@ -69,6 +78,11 @@ int main(int argc, char** argv) {
     a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = N;
     a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = M;
     a.trace = trace + (size_t)l * max_grid * 48;
+    if (variant == 10) {
+      if (epi == 2) { a.xs_out = out; a.ld_xs = N; a.next_scale = gate; a.stats_out = stats; }
+      else { a.ln_stats = stats; a.ln_parts = K / 64; a.ln_c = cd; a.ln_d = cd + N; a.cd_stride = 2 * N; a.cd_rows = 1;
+             a.ln_eps = 1e-6f; a.bias = nullptr; }
+    }
     int rc = epi == 2 ? run_variant<EPI_GATE_RES>(variant, a, st, &bm, &bn)
                       : (epi == 1 ? run_variant<EPI_BF16_GELU>(variant, a, st, &bm, &bn) : run_variant<EPI_BF16>(variant, a, st, &bm, &bn));
     grid = a.tiles_m * a.tiles_n;
