@@ -104,10 +104,11 @@ def main():
 
     log(f"model ready on cuda:{local_rank}, world {world}")
     latency_ms = None
+    isolated_out = None
     for i in range(args.warmup):
         torch.cuda.synchronize()
         tw = time.perf_counter()
-        one_pass()
+        isolated_out = one_pass()
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - tw) * 1e3   # one isolated pass, host prep not overlapped
         log(f"warmup {i} done ({latency_ms:.1f} ms isolated)")
@@ -116,13 +117,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last_out = None
     for _ in range(args.steps):
-        one_pass()
+        last_out = one_pass()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the timed passes are queued back to back (host prep of pass i+1 overlaps the ODE loop of pass i): same inputs and
+    # seed, so the last of them must reproduce the isolated, synchronised warm-up pass bit for bit
+    pipelined_ok = None if isolated_out is None else bool(torch.equal(last_out, isolated_out))
+    if pipelined_ok is False:
+        raise SystemExit("bench: pipelined pass differs from the isolated pass")
     if distributed:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -209,6 +216,7 @@ def main():
                                                                   "on the data path)"},
             "rtf": round(elapsed / gen_audio_s, 5),
             "isolated_pass_ms": None if latency_ms is None else round(latency_ms, 2),
+            "pipelined_equals_isolated": pipelined_ok,
             "generated_mel_frames_per_sec": round(world * args.steps * BATCH * (N_TOTAL - N_REF) / elapsed, 2),
         }
         if roofline is not None:

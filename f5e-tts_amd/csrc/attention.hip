@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
         st[t][r] = sc;
         mx = fmaxf(mx, sc);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(mx);
     const float m_new = fmaxf(m_run, mx);     // finite: every processed tile holds at least one valid key
     const float alpha = fast_exp2(m_run - m_new);  // first tile: exp2(-inf) = 0
     float rs = 0.f;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
         st[t][r] = p;
         rs += p;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = add_xor32(rs);
     l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
         st[t][r] = sc;
         mx = fmaxf(mx, sc);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = fast_exp2(m_run - m_new);
     float rs = 0.f;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
         st[t][r] = p;
         rs += p;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = add_xor32(rs);
     l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll

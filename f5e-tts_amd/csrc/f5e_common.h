@@ -51,10 +51,47 @@ __device__ __forceinline__ bf16x2 f2bf2(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_convertvector(v, bf16x2);
 }
+// Cross-lane adds without the LDS crossbar (__shfl_xor is a ds_bpermute, ~100+ cycles of latency per step on a
+// dependent chain): DPP inside a 16-lane row, v_permlane16/32_swap (gfx950) across rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float add_xor1(float v) { return v + dpp_f32<0xB1>(v); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float add_xor2(float v) { return v + dpp_f32<0x4E>(v); }    // quad_perm [2,3,0,1]
+// v_permlane16/32_swap exchange halves between two registers (gfx950): lanes 16-31 / 48-63 (resp. 32-63) of vdst swap
+// with lanes 0-15 / 32-47 (resp. 0-31) of src.  Started from two copies of v, vdst + src is v + v[lane ^ 16] (resp.
+// ^ 32) in every lane.  Inline asm on purpose: with `__builtin_amdgcn_permlane32_swap(u, u, ...)` hipcc 7.2 folded the
+// two results into one (it emitted r0 + r0; tools/xl_test.hip catches that on the GPU).  The s_nop covers the
+// "VALU write -> v_permlane read" hazard (2 wait states) that the compiler does not see inside asm.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float add_xor16(float v) {  // v + v[lane ^ 16]
+  float a = v, b = v;
+  swap16(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float add_xor32(float v) {  // v + v[lane ^ 32]
+  float a = v, b = v;
+  swap32(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float max_xor32(float v) {  // max(v, v[lane ^ 32])
+  float a = v, b = v;
+  swap32(a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = add_xor1(v);
+  v = add_xor2(v);
+  v += dpp_f32<0x124>(v);  // row_ror:4  -> two quads
+  v += dpp_f32<0x128>(v);  // row_ror:8  -> the 16-lane row
+  v = add_xor16(v);
+  return add_xor32(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -282,8 +282,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (sq + 4 * u < a.ln_parts) sm += pf_st[u][0];
-    sm += __shfl_xor(sm, 1, 64);
-    sm += __shfl_xor(sm, 2, 64);
+    sm = add_xor2(add_xor1(sm));
     const float mean = sm / (float)a.ln_parts;
     const float cols = (float)(a.K / a.ln_parts);
     float m2 = 0.f;
@@ -293,13 +292,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
         const float dm = pf_st[u][0] - mean;
         m2 += pf_st[u][1] + cols * dm * dm;
       }
-    m2 += __shfl_xor(m2, 1, 64);
-    m2 += __shfl_xor(m2, 2, 64);
+    m2 = add_xor2(add_xor1(m2));
     if (sq == 0) {
       fuse_lds[(tid >> 2) * 2] = mean;
       fuse_lds[(tid >> 2) * 2 + 1] = rsqrtf(m2 / (float)a.K + a.ln_eps);
     }
     __syncthreads();
+    if constexpr (DBG == 3) { if (tid == 0) trc[42] = __builtin_amdgcn_s_memtime(); }
   }
   f32x4 xn[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
   if (PREF && EPI == EPI_GATE_RES) {
@@ -343,8 +342,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
           if (a.bias) t += *(const f32x4*)(a.bias + n0 + wn0 + i * 16 + fq * 4);
           ss += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
         }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = add_xor32(add_xor16(ss));
         qk_rn = rsqrtf(ss * (1.0f / 64.0f) + a.qk_eps);
         qk_w = which_w == 0 ? a.qn_w : a.kn_w;
       }
@@ -423,6 +421,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       }
     }
   }
+  if constexpr (DBG == 3) { if (tid == 0) trc[43] = __builtin_amdgcn_s_memtime(); }
   if (FUSE == 2) {
     // (mean, M2) of x_new over this wave's 32 columns, then the two waves of a row pair up through LDS
 #pragma unroll
@@ -430,8 +429,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       float sm = 0.f;
 #pragma unroll
       for (int i = 0; i < TN; ++i) sm += (xn[i][j][0] + xn[i][j][1]) + (xn[i][j][2] + xn[i][j][3]);
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
+      sm = add_xor32(add_xor16(sm));
       const float mw = sm * (1.0f / (float)WN);
       float q2 = 0.f;
 #pragma unroll
@@ -439,8 +437,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
         const f32x4 dv = xn[i][j] - mw;
         q2 += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
       }
-      q2 += __shfl_xor(q2, 16, 64);
-      q2 += __shfl_xor(q2, 32, 64);
+      q2 = add_xor32(add_xor16(q2));
       if (fq == 0) {
         float* slot = fuse_lds + ((wm0 + j * 16 + fr) * WGN + (wave % WGN)) * 2;
         slot[0] = mw;
@@ -448,8 +445,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       }
     }
     // LDS hand-off only: do not drain vmcnt here, the x / xs stores above stay in flight behind the barrier
+    if constexpr (DBG == 3) { if (tid == 0) trc[44] = __builtin_amdgcn_s_memtime(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DBG == 3) { if (tid == 0) trc[45] = __builtin_amdgcn_s_memtime(); }
     if (tid < BM && m0 + tid < a.M) {
       const float ma = fuse_lds[tid * 4], qa = fuse_lds[tid * 4 + 1], mb = fuse_lds[tid * 4 + 2], qb = fuse_lds[tid * 4 + 3];
       const float dm = ma - mb;

@@ -443,16 +443,13 @@ def h2d(t: Tensor, device, dtype=None) -> Tensor:
     return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
-def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
-            timer: Optional[KernelTimer] = None, chains: Optional[int] = None) -> Tensor:
-    """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint, SURVEY App C2).
-
-    Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
-    """
-    cfg, dv = engine.cfg, engine.device
-    B, N, mel = inp.y0.shape
-    nb = len(inp.branches)
-    S = nb * B
+def ode_setup(engine: DiTEngine, inp: SamplerInputs) -> dict:
+    """Host -> device part of an integration: time grid -> (evaluation times, step coefficients), the cached
+    modulation / fused-AdaLN tables, and the small pinned uploads.  Call it on the CALLER's stream, never on the stream
+    that will capture the hipGraph: the pinned-memory allocator later polls the events of these copies
+    (hipEventQuery), and polling an event of a stream that is capturing invalidates that capture (seen with two
+    threads sampling on one model).  It also puts the shared tables on a stream every capture stream waits for."""
+    dv = engine.device
     t = inp.t.detach().to("cpu", torch.float32)
     steps = t.shape[0] - 1
     if inp.method == "euler":
@@ -467,12 +464,29 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         coef = torch.stack((half, dt), 1).reshape(-1)
     else:
         raise _C.F5EError(f"unsupported ODE method {inp.method!r} (euler, midpoint)")
-    E = steps * eps_per_step
+    mod, cd = engine.time_tables_cached(t_eval)                   # [E, 1, row_stride], [E, 1, cd_stride] or None
+    seq_len = h2d(inp.seq_len, dv, I32) if inp.seq_len is not None else None
+    return dict(steps=steps, eps_per_step=eps_per_step, mod=mod, cd=cd if engine.fuse_ln else None,
+                coef_d=h2d(coef, dv).contiguous(), seq_len=seq_len)
+
+
+def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
+            timer: Optional[KernelTimer] = None, chains: Optional[int] = None, setup: Optional[dict] = None) -> Tensor:
+    """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint, SURVEY App C2).
+
+    Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
+    `setup` = ode_setup(engine, inp) made on the caller's stream (required when this runs on a capture stream that other
+    threads' calls may overlap); made here when omitted.
+    """
+    cfg, dv = engine.cfg, engine.device
+    B, N, mel = inp.y0.shape
+    nb = len(inp.branches)
+    S = nb * B
+    if setup is None:
+        setup = ode_setup(engine, inp)
+    steps, eps_per_step, mod, cd = setup["steps"], setup["eps_per_step"], setup["mod"], setup["cd"]
 
     # once-per-call tensors
-    mod, cd = engine.time_tables_cached(t_eval)                   # [E, 1, row_stride], [E, 1, cd_stride] or None
-    if not engine.fuse_ln:
-        cd = None
     in_const = torch.empty(S * N, cfg.dim, device=dv)
     cache: Dict[tuple, Tensor] = {}
     for bi, (da, dt_, dp) in enumerate(inp.branches):
@@ -487,10 +501,8 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             pe = cache[pk]
         engine.input_const(inp.step_cond, cache[tk], pe, da, in_const[bi * B * N:(bi + 1) * B * N])
     rope_cs = engine.rope_table(N)
-    seq_len = None
-    if inp.seq_len is not None:
-        seq_len = h2d(inp.seq_len, dv, I32).repeat(nb).contiguous()
-    coef_d = h2d(coef, dv).contiguous()
+    seq_len = setup["seq_len"].repeat(nb).contiguous() if setup["seq_len"] is not None else None
+    coef_d = setup["coef_d"]
     eval_ptr = torch.zeros(1, dtype=I32, device=dv)
     done = torch.zeros(1, dtype=I32, device=dv)
     n = B * N * mel

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _C
-from ..engine import SamplerInputs, h2d, run_ode
+from ..engine import SamplerInputs, h2d, ode_setup, run_ode
 from .modules import MelSpec
 from .utils import default, exists, intersperse, lens_to_mask, list_str_to_idx, list_str_to_tensor
 
@@ -140,9 +140,10 @@ class CFM(nn.Module):
             side = getattr(self._tls, "stream", None)
             if side is None:
                 side = self._tls.stream = torch.cuda.Stream(device=eng.device)
+            setup = ode_setup(eng, inp)   # pinned uploads + shared tables on the caller's stream, see ode_setup
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains)
+                trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup)
             cur.wait_stream(side)
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)

@@ -126,6 +126,21 @@ int main(int argc, char** argv) {
          med(gap), med(ramp), med(span));
   printf("  per workgroup [cycles, median]: entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
          med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
+  if (variant == 10) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
+    std::vector<double> a42, a43, a44, a45, a40;
+    const int l = L - 1;
+    for (int w = 0; w < grid; ++w) {
+      const unsigned long long* t = &h[((size_t)l * max_grid + w) * 48];
+      a42.push_back((double)(t[42] - t[3])); a43.push_back((double)(t[43] - t[3])); a44.push_back((double)(t[44] - t[3]));
+      a45.push_back((double)(t[45] - t[3])); a40.push_back((double)(t[40] - t[3]));
+    }
+    if (epi == 2)
+      printf("  producer epilogue: stores issued at +%.0f | statistics in LDS +%.0f | barrier passed +%.0f | all stores acknowledged +%.0f\n",
+             med(a43), med(a44), med(a45), med(a40));
+    else
+      printf("  consumer epilogue: statistics reduced +%.0f | stores issued +%.0f | all stores acknowledged +%.0f\n",
+             med(a42), med(a43), med(a40));
+  }
   {  // distribution of per-workgroup start offsets and totals for the last launch
     const int l = L - 1;
     std::vector<double> so, tot;
