@@ -15,44 +15,11 @@
 //     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
 //     16-lane ds_read_b128 groups are conflict free.
 #include "f5e_common.h"
+#include "gemm_bf16_args.h"
 
 namespace {
 
-struct GemmArgs {
-  const bf16* A; int lda;
-  const bf16* W; int ldw;
-  const float* bias;
-  int M, N, K;
-  void* out; int ldo;
-  // gate + residual epilogue
-  float* resid; int ldr;
-  const float* gate; int gate_stride; int gate_rows;
-  const int* eval_ptr; int eval_stride;
-  int rows_per_seq;
-  const int* seq_len;
-  // qkv + rope epilogue
-  bf16* q; bf16* k; bf16* vt;
-  int n_pad; int heads; int rope_heads;
-  const float* cos_sin;  // [rows_per_seq][32][2]
-  const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
-  int tiles_m, tiles_n, m_major;
-  unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
-  // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
-  //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
-  //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - mean c[n]) + d[n]
-  //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
-  //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
-  const float* ln_stats; int ln_parts;
-  const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
-  bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
-};
-
-enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
-
-__device__ __forceinline__ void glds16(const void* g, void* lds) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
-}
+using namespace f5e_gemm;
 
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0() {
@@ -509,6 +476,8 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
     }
   }
+  // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip); hint 9 forces it (tests / tuning)
+  if (sel == 9 || (tile_hint == 0 && a.K >= 128 && blocks(256, 256) >= 512)) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and

@@ -1,0 +1,48 @@
+// Argument block, epilogue ids and the LDS-DMA helper shared by the bf16 GEMM kernels (gemm_bf16.hip: 64x64 .. 128x128
+// ring kernels; gemm_bf16_pp.hip: the 256x256 ping-pong kernel for large M).  Internal to the library (not ABI).
+#pragma once
+#include "f5e_common.h"
+
+namespace f5e_gemm {
+
+struct GemmArgs {
+  const bf16* A; int lda;
+  const bf16* W; int ldw;
+  const float* bias;
+  int M, N, K;
+  void* out; int ldo;
+  // gate + residual epilogue
+  float* resid; int ldr;
+  const float* gate; int gate_stride; int gate_rows;
+  const int* eval_ptr; int eval_stride;
+  int rows_per_seq;
+  const int* seq_len;
+  // qkv + rope epilogue
+  bf16* q; bf16* k; bf16* vt;
+  int n_pad; int heads; int rope_heads;
+  const float* cos_sin;  // [rows_per_seq][32][2]
+  const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
+  int tiles_m, tiles_n, m_major;
+  unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
+  // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
+  //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
+  //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - mean c[n]) + d[n]
+  //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
+  //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
+  const float* ln_stats; int ln_parts;
+  const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
+  bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
+};
+
+enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+
+// gemm_bf16_pp.hip: 256x256 tile, 8 waves in two staggered groups (defined there; epi = EPI_* id)
+int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg = 0);  // dbg 1..3: timing ablations (garbage results)
+
+}  // namespace f5e_gemm

@@ -1,0 +1,315 @@
+// Large-M bf16 GEMM for the DiT block linears: 256 x 256 tile, K-step 64, 8 waves in two groups that run half a phase
+// apart ("ping-pong"): while one group issues its ds_reads and LDS-DMAs the other one is inside its MFMA cluster, so
+// the matrix pipe of every SIMD (one wave of each group per SIMD) stays busy across the workgroup barriers.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]   + the epilogues of gemm_bf16_epilogue.h
+//
+// Why: the 128x128 ring kernel of gemm_bf16.hip tops out at 650-740 TFLOP/s at M = 60k (PMC: matrix pipe 31-35 % busy,
+// 45 % of wave cycles in s_waitcnt / s_barrier): every K-step the whole workgroup stops at one barrier, and a 128x128
+// tile needs 1 byte of L2->LDS fill per 64 flops.  A 256x256 tile halves the fill per flop; the phase structure below
+// (after the CDNA programming guide's "256^2 8-phase" description) takes the barrier off the critical path.
+//
+// Geometry.  wave = wr * 4 + wc owns rows [128 wr, +128) x columns [64 wc, +64) of the tile: acc[4][8] accumulator
+// quads (operands swapped as in gemm_bf16.hip: a quad = 4 consecutive n of one row).  A K-tile (X 256 x 64, W 256 x 64
+// bf16 = 64 KiB) is staged as FOUR half-tiles of 128 rows, grouped by WHEN the waves need them:
+//     XHa: rows {0..63} of both row halves      (the "A0" operands, needed in phase 0 of the K-tile)
+//     WH0: columns {0..31} of all four wc       (the "B0" operands, phase 0)
+//     WH1: columns {32..63} of all four wc      (the "B1" operands, phase 1)
+//     XHb: rows {64..127} of both row halves    (the "A1" operands, phase 2)
+// LDS = 2 K-tile buffers x 4 half-tiles x 16 KiB = 128 KiB, rows of 128 B with the 16-B chunk swizzle c ^ ((row>>1)&7)
+// applied to the DMA source address and to the ds_read_b128 (conflict-free 16-lane groups, as in gemm_bf16.hip).
+//
+// Schedule.  Global phase p = 4 kt + q computes quadrant q of K-tile kt: (A0,B0), (A0,B1), (A1,B1), (A1,B0): 16 MFMAs
+// (64 x 32 outputs x K = 64).  Each phase: [ds_read this phase's new operands; stage half-tile number p + 5 (two
+// global_load_lds per thread); s_waitcnt vmcnt(6)]  s_barrier  [lgkmcnt(0); 16 MFMAs at raised priority]  s_barrier.
+// Half-tiles are staged in the order XHa, WH0, WH1, XHb of K-tile 0, 1, ...; number h is first read in phase
+// h + (h & 3 ? 0 : 1) + ... = {4 kt, 4 kt, 4 kt + 1, 4 kt + 2}, i.e. 5, 4, 4, 4 phases after it was issued.
+//   RAW: vmcnt(6) in phase w leaves only the three youngest half-tiles (issued in phases w-2 .. w) in flight, so
+//        everything first read in phase w + 1 has landed for the issuing wave; the reader passes a barrier that follows
+//        BOTH groups' waits before its phase-(w+1) reads (group 1 runs one barrier late, so the barrier that closes
+//        group 1's wait is the one that opens group 0's next load section).
+//   WAR: a slot is re-staged 8 - 5 = 3 (XHa) or 4 phases after the last ds_read of its previous content; with the
+//        half-phase stagger the late group's reads complete 1.5 phases before the early group's re-stage is issued.
+// The tail shrinks the vmcnt allowance as staging stops (4, 2, 0).
+#include <type_traits>
+
+#include "gemm_bf16_epilogue.h"
+
+namespace {
+
+using namespace f5e_gemm;
+
+constexpr int HALF_BYTES = 128 * 128;  // 128 rows x 64 bf16
+using I0 = std::integral_constant<int, 0>;
+using I1 = std::integral_constant<int, 1>;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int DBG = 0>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware tile order (same bijection as gemm_bf16.hip): blocks sharing blockIdx % 8 walk neighbouring tiles
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  int tile_m, tile_n;
+  if (a.m_major) {
+    tile_m = bid / a.tiles_n;
+    tile_n = bid - tile_m * a.tiles_n;
+  } else {
+    tile_n = bid / a.tiles_m;
+    tile_m = bid - tile_n * a.tiles_m;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // DMA sources: thread tid moves chunks i = tid and tid + 512 of every half-tile; slot row r = i >> 3 holds, at
+  // physical chunk i & 7, the logical chunk (i & 7) ^ ((r >> 1) & 7) of the source row
+  const bf16* src[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 512 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
+    const int xa = m0 + (r >> 6) * 128 + (r & 63), wa = n0 + (r >> 5) * 64 + (r & 31);
+    src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
+    src[1][j] = a.W + (size_t)min(wa, a.N - 1) * a.ldw + c * 8;       // WH0
+    src[2][j] = a.W + (size_t)min(wa + 32, a.N - 1) * a.ldw + c * 8;  // WH1
+    src[3][j] = a.A + (size_t)min(xa + 64, a.M - 1) * a.lda + c * 8;  // XHb
+  }
+  const int KT = a.K / 64, TI = 4 * KT;
+  auto stage = [&](int idx) {
+    const int kt = idx >> 2, type = idx & 3;
+    char* dst = smem + (((kt & 1) << 2) + type) * HALF_BYTES + wave * 1024;
+    const bf16* s0 = type == 0 ? src[0][0] : (type == 1 ? src[1][0] : (type == 2 ? src[2][0] : src[3][0]));
+    const bf16* s1 = type == 0 ? src[0][1] : (type == 1 ? src[1][1] : (type == 2 ? src[2][1] : src[3][1]));
+    glds16(s0 + kt * 64, dst);
+    glds16(s1 + kt * 64, dst + 512 * 16);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a slot: row * 128 + ((c ^ sw) << 4), c = kk * 4 + fq, sw = (fr >> 1) & 7
+  const int sw = (fr >> 1) & 7;
+  const int xoff = (wr * 64 + fr) * 128, woff = (wc * 32 + fr) * 128;
+  bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
+  auto read_x = [&](const char* slot) {
+    if (DBG == 2 || DBG == 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+  auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
+    if (DBG == 2 || DBG == 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+
+  // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
+#pragma unroll
+  for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
+  wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier (half a phase) behind group 0
+
+  auto phase_tail = [&](int p) {  // stage half-tile p + 5, then leave only the 3 youngest half-tiles in flight
+    const int idx = p + 5;
+    if (DBG == 1 || DBG == 4) return;
+    if (idx < TI) stage(idx);
+    const int rem = TI - 1 - idx;  // half-tiles still to be staged after this phase
+    if (rem >= 0) wait_vm<6>();
+    else if (rem == -1) wait_vm<4>();
+    else if (rem == -2) wait_vm<2>();
+    else wait_vm<0>();
+  };
+  auto mfma_quadrant = [&](auto qa_c, auto qb_c, bf16x8 (&wf)[2][2]) {
+    constexpr int qa = decltype(qa_c)::value, qb = decltype(qb_c)::value;  // compile-time accumulator indices
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < ((DBG == 3 || DBG == 4) ? 0 : 2); ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[qb * 2 + i][qa * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[qb * 2 + i][qa * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* buf = smem + ((kt & 1) << 2) * HALF_BYTES;
+    const int p = kt * 4;
+    // phase 0: (A0, B0)
+    read_x(buf);
+    read_w(buf + HALF_BYTES, wf0);
+    phase_tail(p);
+    mfma_quadrant(I0{}, I0{}, wf0);
+    // phase 1: (A0, B1)
+    read_w(buf + 2 * HALF_BYTES, wf1);
+    phase_tail(p + 1);
+    mfma_quadrant(I0{}, I1{}, wf1);
+    // phase 2: (A1, B1)
+    read_x(buf + 3 * HALF_BYTES);
+    phase_tail(p + 2);
+    mfma_quadrant(I1{}, I1{}, wf1);
+    // phase 3: (A1, B0), operands already in registers
+    phase_tail(p + 3);
+    mfma_quadrant(I1{}, I0{}, wf0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+
+  if (DBG == 5) {  // no epilogue: keep the accumulators alive with a store that never happens
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 1.2345e33f) ((float*)a.out)[tid] = s;
+    return;
+  }
+  // ---- epilogue.  With one workgroup per CU nothing hides it, and the MFMA accumulator layout stores 8 B (bf16) or 16 B
+  // (fp32) pieces of 16 different rows per instruction: the memory system sees partial lines (measured: 22 us per
+  // workgroup for 128 KiB of bf16 output).  So the wave's 128 x 64 sub-tile goes through its 16 KiB share of the now
+  // idle LDS ring and leaves as full 128-byte (bf16) / 256-byte (fp32) row segments.  All main-loop LDS reads are
+  // complete here: the balancing barrier above is the last barrier instance of both groups.
+  char* reg = smem + wave * 16384;
+  const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+    if (a.N % 8 == 0 && a.ldo % 8 == 0) {
+      f32x4 bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = min(nbase + i * 16 + fq * 4, a.N - 4);
+        bq[i] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = acc[i][j] + bq[i];
+          if (EPI == EPI_BF16_GELU) v = f32x4{gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3])};
+          // row r: 8 chunks of 16 B (8 bf16), chunk index XORed with r & 7
+          *(bf16x4*)(reg + r * 128 + (((i * 2 + (fq >> 1)) ^ (r & 7)) << 4) + (fq & 1) * 8) = f2bf4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own region, own writes: no workgroup barrier needed
+      const int c = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const int m = mbase + r, n = nbase + c * 8;
+        const uint4 v = *(const uint4*)(reg + r * 128 + ((c ^ (r & 7)) << 4));
+        if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v;
+      }
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_GATE_RES) {
+    if (a.N % 4 == 0) {
+      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
+      f32x4 bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = min(nbase + i * 16 + fq * 4, a.N - 4);
+        bq[i] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const int c = lane & 15;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // 64 rows x 256 B: 16 chunks of 16 B (4 fp32) per row, chunk index XORed with r & 15
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int r = jj * 16 + fr;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *(f32x4*)(reg + r * 256 + (((i * 4 + fq) ^ (r & 15)) << 4)) = acc[i][half * 4 + jj] + bq[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int mb = mbase + half * 64;
+        int seq0 = mb / a.rows_per_seq;
+        int pos0 = mb - seq0 * a.rows_per_seq;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int r = it * 4 + (lane >> 4);
+          const int m = mb + r, n = nbase + c * 4;
+          int seq = seq0, pos = pos0 + r;
+          while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
+          const f32x4 v = *(const f32x4*)(reg + r * 256 + ((c ^ (r & 15)) << 4));
+          const bool live = m < a.M && n < a.N && (a.seq_len == nullptr || pos < a.seq_len[seq]);
+          if (live) {
+            const f32x4 g = *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n);
+            float* xp = a.resid + (size_t)m * a.ldr + n;
+            f32x4 x = *(const f32x4*)xp;
+            x += g * v;
+            *(f32x4*)xp = x;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the region
+      }
+      return;
+    }
+  }
+  gemm_epilogue<EPI, 8, 4>(a, acc, mbase, nbase, lane);
+}
+
+template <int EPI, int DBG = 0>
+int launch_pp_t(GemmArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  a.m_major = a.M > a.N;
+  constexpr int lds = 8 * HALF_BYTES;
+  static bool attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+  F5E_LAUNCH_CHECK("gemm_bf16_pp");
+  return F5E_OK;
+}
+
+}  // namespace
+
+namespace f5e_gemm {
+
+int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
+  F5E_REQUIRE(a.K % 64 == 0 && a.K >= 128, "gemm_bf16_pp: K=%d must be a multiple of 64 and >= 128", a.K);
+  if (dbg == 1) return launch_pp_t<EPI_BF16_GELU, 1>(a, st);
+  if (dbg == 2) return launch_pp_t<EPI_BF16_GELU, 2>(a, st);
+  if (dbg == 3) return launch_pp_t<EPI_BF16_GELU, 3>(a, st);
+  if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
+  if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
+  switch (epi) {
+    case EPI_BF16: return launch_pp_t<EPI_BF16>(a, st);
+    case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU>(a, st);
+    case EPI_GATE_RES: return launch_pp_t<EPI_GATE_RES>(a, st);
+    case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE>(a, st);
+    case EPI_F32: return launch_pp_t<EPI_F32>(a, st);
+  }
+  f5e_set_error("gemm_bf16_pp: unknown epilogue %d", epi);
+  return F5E_ERR_BAD_SHAPE;
+}
+
+}  // namespace f5e_gemm

@@ -54,6 +54,25 @@ def test_dit_sample_single_forward(B, N, masked):
         assert float((out.cpu() - ref).abs().max()) < 0.03 * float(ref.abs().max())
 
 
+def test_large_batch_forward_takes_the_pingpong_gemm():
+    """B = 14 x N = 938 rows (13 132 >= the 256x256-tile threshold for the QKV and FF1 linears): the ping-pong GEMM kernel
+    (gemm_bf16_pp.hip) is selected automatically; masked batch, against the fp32 oracle."""
+    cfg = O.DiTConfig(**dict(SMALL, depth=1))
+    sd, dit, _ = build(cfg)
+    B, N = 14, 938
+    g = torch.Generator().manual_seed(15)
+    x, cond = torch.randn(B, N, 100, generator=g), torch.randn(B, N, 100, generator=g)
+    text = torch.randint(0, 300, (B, 40), generator=g)
+    lens = torch.tensor([N - 17 * i for i in range(B)])
+    mask = torch.arange(N)[None] < lens[:, None]
+    tm = torch.linspace(0.1, 0.9, B)
+    ref = O.dit_sample(sd, cfg, x, cond, text, None, tm, False, False, False, mask)
+    out = dit.sample(x.cuda(), cond.cuda(), text.cuda(), None, tm.cuda(), False, False, False, mask.cuda())
+    valid = mask[..., None].expand_as(ref)
+    assert rel_l2(out.cpu()[valid], ref[valid]) < 1e-2, rel_l2(out.cpu()[valid], ref[valid])
+    assert float((out.cpu() - ref)[valid].abs().max()) < 0.03 * float(ref[valid].abs().max())
+
+
 def test_ditblock_api():
     from f5e_tts_amd.model import DiTBlock
     cfg = O.DiTConfig(**SMALL)

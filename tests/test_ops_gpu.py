@@ -39,7 +39,10 @@ def close(a, b, rtol, atol, what=""):
 
 
 @pytest.mark.parametrize("M,N,K,hint", [(938, 2048, 1024, 0), (938, 1024, 2048, 1), (130, 192, 128, 2), (77, 100, 64, 3),
-                                        (1, 64, 64, 0), (256, 256, 256, 1)])
+                                        (1, 64, 64, 0), (256, 256, 256, 1),
+                                        # hint 9 = the 256x256 ping-pong kernel (auto-selected at large M)
+                                        (938, 2048, 1024, 9), (700, 768, 512, 9), (300, 100, 128, 9), (256, 256, 128, 9),
+                                        (1300, 512, 2048, 9)])
 def test_gemm_bf16_bias(ops, M, N, K, hint):
     a = torch.randn(M, K, generator=g(1)).to(BF)
     w = (torch.randn(N, K, generator=g(2)) / math.sqrt(K)).to(BF)
@@ -57,17 +60,18 @@ def test_gemm_bf16_bias(ops, M, N, K, hint):
 
 def test_gemm_bf16_identity_asymmetric(ops):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
-    n = 128
-    a = torch.eye(n).to(BF)
-    w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)  # exactly representable, asymmetric
-    out = torch.empty(n, n, device="cuda")
-    for hint in (1, 2, 3):
-        ops.gemm_bf16_bias(dev(a), dev(w), None, out, tile_hint=hint)
-        assert torch.equal(out.cpu(), w.float().T), f"tile {hint}"
+    for n, hints in ((128, (1, 2, 3)), (512, (1, 9))):
+        a = torch.eye(n).to(BF)
+        w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)  # exactly representable, asymmetric
+        out = torch.empty(n, n, device="cuda")
+        for hint in hints:
+            ops.gemm_bf16_bias(dev(a), dev(w), None, out, tile_hint=hint)
+            assert torch.equal(out.cpu(), w.float().T), f"n {n} tile {hint}"
 
 
-@pytest.mark.parametrize("M,N,K,rps", [(938, 1024, 1024, 469), (200, 256, 512, 50)])
-def test_gemm_bf16_gate_residual(ops, M, N, K, rps):
+@pytest.mark.parametrize("M,N,K,rps,hint", [(938, 1024, 1024, 469, 0), (200, 256, 512, 50, 0), (938, 1024, 2048, 469, 9),
+                                            (600, 768, 256, 100, 9)])
+def test_gemm_bf16_gate_residual(ops, M, N, K, rps, hint):
     S = M // rps
     a = torch.randn(M, K, generator=g(4)).to(BF)
     w = (torch.randn(N, K, generator=g(5)) / math.sqrt(K)).to(BF)
@@ -88,13 +92,14 @@ def test_gemm_bf16_gate_residual(ops, M, N, K, rps):
     td = dev(table)
     ev = torch.tensor([e], dtype=torch.int32, device="cuda")
     ops.gemm_bf16_gate_residual(dev(a), dev(w), dev(b), xd, td[0, :, N:2 * N], rps, seq_len=dev(lens), eval_ptr=ev,
-                                eval_stride=table.stride(0))
+                                eval_stride=table.stride(0), tile_hint=hint)
     close(xd, ref, 1e-4, 2e-4, "gate residual")
     assert gate_view.shape == (2, N)
 
 
-@pytest.mark.parametrize("S,N,H,rope_heads,K", [(2, 469, 16, 16, 1024), (3, 70, 2, 1, 128)])
-def test_qkv_rope(ops, S, N, H, rope_heads, K):
+@pytest.mark.parametrize("S,N,H,rope_heads,K,hint", [(2, 469, 16, 16, 1024, 0), (3, 70, 2, 1, 128, 0), (2, 469, 16, 16, 1024, 9),
+                                                     (3, 150, 12, 1, 768, 9)])
+def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     inner = H * 64
     n_pad = (N + 63) // 64 * 64
     a = torch.randn(S * N, K, generator=g(9)).to(BF)
@@ -114,7 +119,7 @@ def test_qkv_rope(ops, S, N, H, rope_heads, K):
     q = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
     k = torch.zeros_like(q)
     vt = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
-    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, rope_heads, cs, N)
+    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, rope_heads, cs, N, tile_hint=hint)
     qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)   # fragment-major layouts -> [pos, d]
     unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
     close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
@@ -346,7 +351,8 @@ def test_istft_head(ops, B, T):
     close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "istft")
 
 
-def test_qkv_rope_with_qk_rmsnorm(ops):
+@pytest.mark.parametrize("hint", [0, 9])
+def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     """qk_norm = 'rms_norm' (reference modules.py:464-467): RMSNorm over the 64-d head before RoPE, q and k only."""
     S, N, H, K = 2, 150, 12, 768
     inner, n_pad = H * 64, 192
@@ -362,7 +368,8 @@ def test_qkv_rope_with_qk_rmsnorm(ops):
     ops.rope_table(dev(1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))), cs)
     q = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
     k, vt = torch.zeros_like(q), torch.zeros_like(q)
-    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, H, cs, N, q_norm_w=dev(qw), k_norm_w=dev(kw))
+    ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, H, cs, N, q_norm_w=dev(qw), k_norm_w=dev(kw),
+                           tile_hint=hint)
     qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)
     unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
     close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q normed")

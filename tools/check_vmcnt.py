@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as td:
                            "--cuda-device-only", "-Wno-unused-value", src, "-o", out])
     lines = open(out).read().split("\n")
 
-kern = re.compile(r"_ZN12_GLOBAL__N_116gemm_bf16_kernelI((?:Li\d+E)+)EEvNS_8GemmArgsE:")
+kern = re.compile(r"_ZN12_GLOBAL__N_116gemm_bf16_kernelI((?:Li\d+E)+)EEvN8f5e_gemm8GemmArgsE:")
 cur, body = None, {}
 for ln in lines:
     m = kern.match(ln)
