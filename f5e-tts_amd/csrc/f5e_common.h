@@ -99,10 +99,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))); tanh(u) = 1 - 2/(1+exp(2u))
-  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-  return 0.5f * x * (1.0f + t);
+  // 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u))  ==  x * rcp(1 + exp2(x * p(x^2))),
+  // p(t) = -2 sqrt(2/pi) log2(e) (1 + 0.044715 t): 3 mul + 1 fma + 1 add and two quarter-rate ops (v_exp_f32, v_rcp_f32).
+  // The epilogue of a 256 x 256 GEMM tile applies this to 128 values per lane with nothing to hide behind, so the IEEE
+  // division of the textbook form (~10 instructions) matters; v_rcp_f32 is good to 1 ulp, the result is rounded to bf16.
+  const float t = x * x;
+  const float p = __builtin_fmaf(t, -2.0f * 0.7978845608028654f * 1.4426950408889634f * 0.044715f,
+                                 -2.0f * 0.7978845608028654f * 1.4426950408889634f);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -32,6 +32,7 @@ struct GemmArgs {
   const float* ln_stats; int ln_parts;
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
+  int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };

@@ -31,6 +31,7 @@
 //   WAR: a slot is re-staged 8 - 5 = 3 (XHa) or 4 phases after the last ds_read of its previous content; with the
 //        half-phase stagger the late group's reads complete 1.5 phases before the early group's re-stage is issued.
 // The tail shrinks the vmcnt allowance as staging stops (4, 2, 0).
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_bf16_epilogue.h"
@@ -48,9 +49,8 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int DBG = 0>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int EPI, int DBG>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
+__device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
 
   // XCD-aware tile order (same bijection as gemm_bf16.hip): blocks sharing blockIdx % 8 walk neighbouring tiles
-  int bid = blockIdx.x;
+  int bid = phys_id;
   {
-    const int nblk = gridDim.x;
+    const int nblk = n_tiles;
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
         const int r = it * 8 + (lane >> 3);
         const int m = mbase + r, n = nbase + c * 8;
         const uint4 v = *(const uint4*)(reg + r * 128 + ((c ^ (r & 7)) << 4));
-        if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v;
+        if (DBG == 6) { if (v.x == 0x7fc1u && m < 0) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v; }  // no stores
+        else if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v;
       }
       return;
     }
@@ -271,7 +272,94 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
       return;
     }
   }
+  if constexpr (EPI == EPI_QKV_ROPE) {
+    // V goes out transposed inside 16-key groups ([group][d / 32][d % 32][h][j], attention.hip): from the accumulator
+    // layout that is four 2-byte stores per quad (61 M scattered 2-byte stores per launch at C3).  A wave with V columns
+    // (one head: 64 d) parks its 128 x 64 sub-tile in LDS and writes 16-byte pieces = 8 keys of one d instead; whole
+    // groups leave as 1 KiB contiguous per instruction.  Positions restart at every sequence, so the wave's rows split
+    // into at most two segments (rows_per_seq >= 128) whose first / last group may be partial: those fall back to
+    // element stores of the valid keys only (the other keys of the group belong to a neighbouring wave).
+    const int inner = a.heads * 64;
+    if (nbase >= 2 * inner && a.rows_per_seq >= 128) {
+      const int head = (nbase - 2 * inner) >> 6;
+      f32x4 bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bq[i] = a.bias ? *(const f32x4*)(a.bias + nbase + i * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = acc[i][j] + bq[i];
+          *(bf16x4*)(reg + r * 128 + (((i * 2 + (fq >> 1)) ^ (r & 7)) << 4) + (fq & 1) * 8) = f2bf4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int rows_valid = min(128, a.M - mbase);
+      const int seq0 = mbase / a.rows_per_seq, pos0 = mbase - seq0 * a.rows_per_seq;
+      const int rb = min(128, a.rows_per_seq - pos0);  // rows [0, rb) are sequence seq0, [rb, 128) sequence seq0 + 1
+      const int dl = lane >> 1, hk = lane & 1;
+      for (int seg = 0; seg < 2; ++seg) {
+        const int rstart = seg == 0 ? 0 : rb;
+        const int rcount = min(seg == 0 ? rb : 128 - rb, rows_valid - rstart);
+        if (rcount <= 0) break;
+        const int pstart = seg == 0 ? pos0 : 0;
+        bf16* vb = a.vt + ((size_t)(seq0 + seg) * a.heads + head) * a.n_pad * 64;
+        for (int G = pstart >> 4; G <= (pstart + rcount - 1) >> 4; ++G) {
+          const bool whole = G * 16 >= pstart && G * 16 + 15 < pstart + rcount;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int d = dt * 32 + dl;
+            bf16x8 piece;
+            bool ok[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int pos = G * 16 + 8 * (j >> 2) + 4 * hk + (j & 3);
+              ok[j] = pos >= pstart && pos < pstart + rcount;
+              const int r = ok[j] ? rstart + pos - pstart : 0;
+              piece[j] = *(const bf16*)(reg + r * 128 + (((d >> 3) ^ (r & 7)) << 4) + (d & 7) * 2);
+            }
+            bf16* dst = vb + ((size_t)(G * 2 + dt) * 32 + dl) * 16 + hk * 8;
+            if (whole) {
+              *(bf16x8*)dst = piece;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (ok[j]) dst[j] = piece[j];
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   gemm_epilogue<EPI, 8, 4>(a, acc, mbase, nbase, lane);
+}
+
+// Persistent launch: one workgroup per CU walks tiles phys_id = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of
+// 8, so a workgroup keeps its XCD class and the XCD-aware order of pp_tile is unchanged).  Two reasons.  (1) With 128 KiB
+// of LDS only one workgroup fits a CU, so nothing overlaps a workgroup's exit (store acknowledgement) and its
+// successor's launch + cold prologue; in a loop the next tile's prologue DMAs are issued right behind the stores.
+// (2) All CUs run the same tile schedule in lock step: 256 CUs finish their K loops together and store 32 MiB in one
+// burst, each waiting for the whole burst to drain (the stores cost 63 of 310 us at C3's FF1, the HBM being idle the
+// rest of the time).  Workgroups that own one tile fewer than the busiest ones (n_tiles % gridDim.x != 0) have a tile time of
+// slack: they start late by an even share of it, which takes the CUs out of phase at no cost in makespan.
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
+  const int extra = n_tiles % grid;  // workgroups [0, extra) own one more tile
+  if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
+    // ~5000 cycles per K-tile measured; s_sleep 127 = 8128 cycles
+    const long long slack = (long long)(a.K / 64) * 5000;
+    const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  for (int p = blockIdx.x; p < n_tiles; p += grid) {
+    pp_tile<EPI, DBG>(a, smem, p, n_tiles);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
+    __builtin_amdgcn_s_barrier();
+  }
 }
 
 template <int EPI, int DBG = 0>
@@ -285,7 +373,20 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    n_cu = v > 0 ? v / 8 * 8 : 256;
+    if (n_cu == 0) n_cu = 8;
+  }
+  const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
+  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
+  const int n_tiles = a.tiles_m * a.tiles_n;
+  const char* pe = getenv("F5E_PP_PERSIST");  // read every launch: A/B switch for tuning runs
+  const int grid = (pe && pe[0] == '0') ? n_tiles : (n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu);
+  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG>), dim3(grid), dim3(512), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_pp");
   return F5E_OK;
 }
@@ -301,6 +402,7 @@ int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
   if (dbg == 3) return launch_pp_t<EPI_BF16_GELU, 3>(a, st);
   if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
   if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
+  if (dbg == 6) return launch_pp_t<EPI_BF16_GELU, 6>(a, st);
   switch (epi) {
     case EPI_BF16: return launch_pp_t<EPI_BF16>(a, st);
     case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU>(a, st);

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from f5e_tts_amd import ops
 BF = torch.bfloat16
-M, N, K = int(sys.argv[1]) if len(sys.argv) > 1 else 60032, 2048, 1024
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 60032
+N, K = int(os.environ.get("N", "2048")), int(os.environ.get("K", "1024"))
 a = torch.randn(M, K, device="cuda").to(BF)
 ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(BF) for _ in range(8)]
 b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=BF)
