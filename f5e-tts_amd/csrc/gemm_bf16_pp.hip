@@ -251,20 +251,33 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
         const int mb = mbase + half * 64;
         int seq0 = mb / a.rows_per_seq;
         int pos0 = mb - seq0 * a.rows_per_seq;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-          const int r = it * 4 + (lane >> 4);
-          const int m = mb + r, n = nbase + c * 4;
-          int seq = seq0, pos = pos0 + r;
-          while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
-          const f32x4 v = *(const f32x4*)(reg + r * 256 + ((c ^ (r & 15)) << 4));
-          const bool live = m < a.M && n < a.N && (a.seq_len == nullptr || pos < a.seq_len[seq]);
-          if (live) {
-            const f32x4 g = *(const f32x4*)(a.gate + eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + n);
-            float* xp = a.resid + (size_t)m * a.ldr + n;
-            f32x4 x = *(const f32x4*)xp;
-            x += g * v;
-            *(f32x4*)xp = x;
+        // 8 rows per lane at a time: every load of a batch (x, gate row, sequence length) is issued from a clamped
+        // address before the first use, so a batch costs one memory round trip instead of two per row
+#pragma unroll
+        for (int b8 = 0; b8 < 2; ++b8) {
+          f32x4 xv[8], gv[8];
+          int len[8], ps[8];
+          bool inb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = (b8 * 8 + u) * 4 + (lane >> 4);
+            const int m = mb + r, n = nbase + c * 4;
+            int seq = seq0, pos = pos0 + r;
+            while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
+            inb[u] = m < a.M && n < a.N;
+            ps[u] = pos;
+            const int mc = min(m, a.M - 1), nc = min(n, a.N - 4);
+            const int sc = inb[u] ? seq : mc / a.rows_per_seq;
+            len[u] = a.seq_len ? a.seq_len[sc] : a.rows_per_seq;
+            gv[u] = *(const f32x4*)(a.gate + eoff + (size_t)(sc % a.gate_rows) * a.gate_stride + nc);
+            xv[u] = *(const f32x4*)(a.resid + (size_t)mc * a.ldr + nc);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = (b8 * 8 + u) * 4 + (lane >> 4);
+            const f32x4 v = *(const f32x4*)(reg + r * 256 + ((c ^ (r & 15)) << 4));
+            if (inb[u] && ps[u] < len[u])
+              *(f32x4*)(a.resid + (size_t)(mb + r) * a.ldr + nbase + c * 4) = xv[u] + gv[u] * v;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the region
@@ -333,6 +346,65 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
       return;
     }
   }
+  if constexpr (EPI == EPI_QKV_ROPE) {
+    // q / k waves (one head each): the destination offset in the fragment-major layout and the cos/sin offset both split
+    // into a row part (sequence, position) and a column part (d), so a quad costs one add per address instead of the
+    // divisions and 64-bit chains of the generic epilogue (32 quads per lane with nothing to hide behind).
+    const int inner = a.heads * 64;
+    if (nbase < 2 * inner) {
+      const int which = nbase >= inner ? 1 : 0;
+      const int head = (nbase - which * inner) >> 6;
+      bf16* base = (which == 0 ? a.q : a.k) + (size_t)head * a.n_pad * 64;
+      const bool rope_on = head < a.rope_heads;
+      const float* qk_w = a.qn_w ? (which == 0 ? a.qn_w : a.kn_w) : nullptr;
+      f32x4 bq[4], wq[4];
+      int coloff[4], csoff[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = i * 16 + fq * 4;
+        bq[i] = a.bias ? *(const f32x4*)(a.bias + nbase + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wq[i] = qk_w ? *(const f32x4*)(qk_w + d) : f32x4{1.f, 1.f, 1.f, 1.f};
+        coloff[i] = i * 512 + (fq >> 1) * 8 + (fq & 1) * 4;
+        csoff[i] = d;  // (d >> 1) * 2 floats
+      }
+      const int seq0 = mbase / a.rows_per_seq, pos0 = mbase - seq0 * a.rows_per_seq;
+      const size_t seq_stride = (size_t)a.heads * a.n_pad * 64;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = j * 16 + fr;
+        if (mbase + r >= a.M) continue;
+        int seq = seq0, pos = pos0 + r;
+        while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
+        bf16* rowp = base + seq * seq_stride + (size_t)(pos >> 5) * 2048 + (pos & 31) * 16;
+        const float* csrow = a.cos_sin + (size_t)pos * 64;
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[i][j] + bq[i];
+        if (qk_w) {  // RMSNorm over the head's 64 values: 16 in this lane, 48 in the lanes fr + 16 / 32 / 48
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+          ss = add_xor32(add_xor16(ss));
+          const float rn = rsqrtf(ss * (1.0f / 64.0f) + a.qk_eps);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] * rn * wq[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 o = v[i];
+          if (rope_on) {
+            const f32x4 cs = *(const f32x4*)(csrow + csoff[i]);
+            o[0] = v[i][0] * cs[0] - v[i][1] * cs[1];
+            o[1] = v[i][1] * cs[0] + v[i][0] * cs[1];
+            o[2] = v[i][2] * cs[2] - v[i][3] * cs[3];
+            o[3] = v[i][3] * cs[2] + v[i][2] * cs[3];
+          }
+          *(bf16x4*)(rowp + coloff[i]) = f2bf4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      return;
+    }
+  }
   gemm_epilogue<EPI, 8, 4>(a, acc, mbase, nbase, lane);
 }
 
@@ -349,7 +421,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
   const int extra = n_tiles % grid;  // workgroups [0, extra) own one more tile
-  if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
+  if (a.pp_stagger == 2) {  // experiment: every workgroup, quarter-tile steps
+    const long long slack = (long long)(a.K / 64) * 5000;
+    const int naps = (int)(slack * (((int)blockIdx.x >> 3) & 3) / 4 / 8128);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  } else if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
     // ~5000 cycles per K-tile measured; s_sleep 127 = 8128 cycles
     const long long slack = (long long)(a.K / 64) * 5000;
     const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
@@ -382,7 +458,7 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
     if (n_cu == 0) n_cu = 8;
   }
   const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
-  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
+  a.pp_stagger = (se && se[0] == '0') ? 0 : ((se && se[0] == '2') ? 2 : 1);
   const int n_tiles = a.tiles_m * a.tiles_n;
   const char* pe = getenv("F5E_PP_PERSIST");  // read every launch: A/B switch for tuning runs
   const int grid = (pe && pe[0] == '0') ? n_tiles : (n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu);

@@ -17,7 +17,8 @@ def timeit(fn, reps=16):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 modes = {"dynamic": {"F5E_PP_PERSIST": "0"}, "persist": {"F5E_PP_PERSIST": "1", "F5E_PP_STAGGER": "0"},
-         "persist+stagger": {"F5E_PP_PERSIST": "1", "F5E_PP_STAGGER": "1"}}
+         "persist+stagger": {"F5E_PP_PERSIST": "1", "F5E_PP_STAGGER": "1"},
+         "stagger-all": {"F5E_PP_PERSIST": "1", "F5E_PP_STAGGER": "2"}}
 for name, N, K in (("QKV", 3072, 1024), ("OUT", 1024, 1024), ("FF1", 2048, 1024), ("FF2", 1024, 2048)):
     a = torch.randn(M, K, device="cuda").to(BF)
     ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(BF) for _ in range(6)]
