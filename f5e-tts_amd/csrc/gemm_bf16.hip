@@ -178,12 +178,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
         pf_d[i][j] = ldv4(a.ln_d + roff + nc);                       // counted
       }
     }
-    // row statistics: 4 threads per row of the tile, each takes every 4th 64-column partial (<= 32 partials)
-    const int srow = min(m0 + (tid >> 2), a.M - 1), sq = tid & 3;
+    // row statistics: 4 threads per row of the tile, each takes ln_parts / 4 CONSECUTIVE 64-column partials (<= 8), so
+    // the 64 lanes of a wave read one contiguous range of [M][parts][2] instead of 16 strided rows per instruction
+    // (ln_parts % 4 == 0: D is a multiple of 256).  Entries past the thread's share repeat its last one (not summed).
+    const int pp = a.ln_parts >> 2;
+    const long long last = (long long)a.M * a.ln_parts - 1;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int part = min(sq + 4 * u, a.ln_parts - 1);
-      pf_st[u] = *(const f32x2*)(a.ln_stats + ((size_t)srow * a.ln_parts + part) * 2);  // counted
+      const long long e = (long long)m0 * a.ln_parts + tid * pp + min(u, pp - 1);
+      pf_st[u] = *(const f32x2*)(a.ln_stats + (size_t)(e < last ? e : last) * 2);  // counted
     }
   }
   if (PREF) {  // not counted: may be skipped
@@ -244,18 +247,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   if (FUSE == 1) {
     // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
     // M2 = sum_p M2_p + 64 sum_p (mean_p - mean)^2, rstd = rsqrt(M2 / K + eps)
-    const int sq = tid & 3;
+    const int sq = tid & 3, pp = a.ln_parts >> 2;
     float sm = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (sq + 4 * u < a.ln_parts) sm += pf_st[u][0];
+      if (u < pp) sm += pf_st[u][0];
     sm = add_xor2(add_xor1(sm));
     const float mean = sm / (float)a.ln_parts;
     const float cols = (float)(a.K / a.ln_parts);
     float m2 = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (sq + 4 * u < a.ln_parts) {
+      if (u < pp) {
         const float dm = pf_st[u][0] - mean;
         m2 += pf_st[u][1] + cols * dm * dm;
       }
@@ -531,7 +534,7 @@ int check_common(const GemmArgs& a) {
 int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
   if (!ln || !ln->stats) return F5E_OK;
   F5E_REQUIRE(bias == nullptr, "gemm_bf16: with fused AdaLN the bias is part of the d table");
-  F5E_REQUIRE(ln->c && ln->d && ln->parts > 0 && ln->parts <= 32 && a.K % ln->parts == 0 && ln->cd_rows > 0 &&
+  F5E_REQUIRE(ln->c && ln->d && ln->parts > 0 && ln->parts <= 32 && ln->parts % 4 == 0 && a.K % ln->parts == 0 && ln->cd_rows > 0 &&
                   ln->cd_stride % 4 == 0 && ln->cd_eval_stride % 4 == 0 && ln->rows_per_seq > 0,
               "gemm_bf16: bad fused-AdaLN consumer arguments (parts=%d)", ln->parts);
   a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;

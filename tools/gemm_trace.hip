@@ -1,6 +1,7 @@
 // Per-workgroup timeline of the bf16 GEMM kernel (diagnostic build, DBG == 3 stamps) inside a chain of dependent
 // launches replayed from a hipGraph.  Answers: where do the microseconds of a small-M launch go (launch gap, start
 // ramp, first tile, K loop, epilogue)?    usage: gemm_trace.bin <variant> <M> <N> <K> <epi: 0 bf16, 1 gelu, 2 gate_res>
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_trace.hip f5e-tts_amd/csrc/gemm_bf16_pp.hip -o tools/gemm_trace.bin
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
