@@ -123,36 +123,42 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
     // ---- online softmax (log2 domain) ----
     const int key_base = cur * 64 + 4 * hh;
     const bool partial = (cur * 64 + 64 > kv_len);
+    // The softmax VALU work (32 scores per lane and tile), not the MFMAs, bounds this kernel: the maximum is taken over
+    // the raw scores (the scale is positive), scale and subtraction fold into one fma in front of exp2, and the running
+    // maximum is only moved -- with the 32-multiply rescale of the accumulators -- when some query of the wave gained more
+    // than 2^8 on it: p <= 256 keeps fp32 sums and the bf16 P operand as accurate as before, and (m, l, O) stay
+    // consistent, so the final O / l is unchanged mathematically.
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float sc = st[t][r] * a.scale_log2e;
         if (partial) {
           const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= kv_len) sc = -INFINITY;
+          if (key >= kv_len) st[t][r] = -INFINITY;
         }
-        st[t][r] = sc;
-        mx = fmaxf(mx, sc);
+        mx = fmaxf(mx, st[t][r]);
       }
-    mx = max_xor32(mx);
-    const float m_new = fmaxf(m_run, mx);     // finite: every processed tile holds at least one valid key
-    const float alpha = fast_exp2(m_run - m_new);  // first tile: exp2(-inf) = 0
+    mx = max_xor32(mx) * a.scale_log2e;           // finite: every processed tile holds at least one valid key
+    const bool jump = mx - m_run > 8.0f;          // first tile: m_run = -inf
+    if (__builtin_amdgcn_ballot_w64(jump) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);  // first tile: exp2(-inf) = 0
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(st[t][r] - m_new);
+        const float p = fast_exp2(__builtin_fmaf(st[t][r], a.scale_log2e, -m_run));
         st[t][r] = p;
         rs += p;
       }
-    rs = add_xor32(rs);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    l_run += add_xor32(rs);
 
     // ---- O^T += V^T . P^T ; k-step (t, s): accumulator regs 8s..8s+7 of st[t] are exactly the B fragment ----
 #pragma unroll
@@ -297,36 +303,38 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
     }
     const int key_base = t64 * 64 + 4 * hh;
     const bool partial = (t64 * 64 + 64 > kv_len);
+    // same softmax as attn_fwd_kernel: raw maximum, scale folded into the fma, running maximum moved lazily (> 2^8)
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float sc = st[t][r] * a.scale_log2e;
         if (partial) {
           const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= kv_len) sc = -INFINITY;
+          if (key >= kv_len) st[t][r] = -INFINITY;
         }
-        st[t][r] = sc;
-        mx = fmaxf(mx, sc);
+        mx = fmaxf(mx, st[t][r]);
       }
-    mx = max_xor32(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = fast_exp2(m_run - m_new);
+    mx = max_xor32(mx) * a.scale_log2e;
+    const bool jump = mx - m_run > 8.0f;
+    if (__builtin_amdgcn_ballot_w64(jump) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(st[t][r] - m_new);
+        const float p = fast_exp2(__builtin_fmaf(st[t][r], a.scale_log2e, -m_run));
         st[t][r] = p;
         rs += p;
       }
-    rs = add_xor32(rs);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    l_run += add_xor32(rs);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
