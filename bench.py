@@ -56,12 +56,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3"],
-                    help="C2 (default, the graded line): batch 1, 2 s ref / 5 s total; C3: batch 32, 4 s / 10 s")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="C2 (default, the graded line): batch 1, 2 s ref / 5 s total; C3: batch 32, 4 s / 10 s; "
+                         "C4: eval_infer_batch-style stream of single utterances (LibriSpeech-PC length mix, NFE 16, "
+                         "LPT-sharded over the ranks, a step = one utterance); C5: Small + PPG config, sample_vc, NFE 32")
     args = ap.parse_args()
-    global N_REF, N_TOTAL, BATCH
+    global N_REF, N_TOTAL, BATCH, NFE
     if args.workload == "C3":
         N_REF, N_TOTAL, BATCH = 375, 938, 32
+    if args.workload == "C4":
+        NFE = 16
+    if args.workload in ("C4", "C5"):
+        args.no_roofline = True   # the in-situ GEMM timing is set up for the v1_Base shapes of C2 / C3
 
     import torch
     import torch.distributed as dist
@@ -86,11 +92,20 @@ def main():
     from oracle import f5e_oracle as O  # only for seeded synthetic inputs/weights and the cpu_baseline leg
 
     ops.require_device()
-    cfg = O.DiTConfig()
-    sd = O.init_dit_state(cfg, 1234)
-    dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
-    dit.load_state_dict(sd, strict=True)
-    cfm = CFM(transformer=dit).cuda().eval()
+    if args.workload == "C5":   # BASELINE config 5: configs/F5TTS_Small_PPG.yaml (dim 768, 18 blocks, PPG input)
+        cfg = O.DiTConfig(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
+                          text_mask_padding=False, pe_attn_head=1, use_ppg=True, ppg_dim=256)
+        ppg_config = dict(use_ppg=True, ppg_dim=256, use_transformer=False)
+        dit = DiT(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
+                  text_mask_padding=False, pe_attn_head=1, ppg_config=ppg_config)
+        dit.load_state_dict(O.init_dit_state(cfg, 1234), strict=True)
+        cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
+    else:
+        cfg = O.DiTConfig()
+        sd = O.init_dit_state(cfg, 1234)
+        dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
+        dit.load_state_dict(sd, strict=True)
+        cfm = CFM(transformer=dit).cuda().eval()
     vs = O.init_vocos_state()
     voc = Vocos()
     voc.load_state_dict(vs, strict=False)
@@ -101,6 +116,38 @@ def main():
     def one_pass():
         mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
         return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
+
+    step_frames = None       # per-step (total, generated) frame counts when the steps differ (C4)
+    if args.workload == "C5":
+        g5 = torch.Generator().manual_seed(55)
+        ppg = torch.randn(1, round(0.533 * N_TOTAL), 256, generator=g5).cuda()
+
+        def one_pass():  # noqa: F811  reference eval_infer_batch_vc.py:214-224 (alpha_spk 2.5, alpha_ppg 3)
+            mel, _ = cfm.sample_vc(wav, ppg, duration=N_TOTAL, steps=NFE, alpha_spk=2.5, alpha_ppg=3.0,
+                                   sway_sampling_coef=SWAY, seed=0)
+            return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
+    if args.workload == "C4":
+        from f5e_tts_amd.eval.eval_infer_batch import flop_fwd, lpt_partition
+        utts = []
+        with open(os.path.join(ROOT, "tests", "golden", "c4_durations.csv")) as f:
+            for line in f:
+                if line.startswith("#"):
+                    continue
+                rs, rb, _gs, gb = line.split(",")
+                ref_len = int(float(rs) * 24000) // 256
+                utts.append((ref_len, ref_len + int(ref_len / (int(rb) + 1) * int(gb))))   # utils_eval.py:337-339
+        need = world * (args.steps + args.warmup)
+        utts = [utts[i % len(utts)] for i in range(need)]
+        mine = [utts[i] for i in lpt_partition([flop_fwd(t) for _, t in utts], world)[rank]]
+        inputs = [(O.synthetic_ref_wave(r).cuda(), O.synthetic_text_ids(t), r, t) for r, t in mine]
+        step_frames = [(t, t - r) for _, _, r, t in inputs[args.warmup:]]
+        cursor = [0]
+
+        def one_pass():  # noqa: F811  one utterance per call, as reference eval_infer_batch.py:196-216
+            w, ids, r, t = inputs[cursor[0] % len(inputs)]
+            cursor[0] += 1
+            mel, _ = cfm.sample(w, ids, duration=t, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+            return voc.decode(mel[:, r:t, :].permute(0, 2, 1))
 
     log(f"model ready on cuda:{local_rank}, world {world}")
     latency_ms = None
@@ -127,7 +174,9 @@ def main():
     elapsed = time.perf_counter() - t0
     # the timed passes are queued back to back (host prep of pass i+1 overlaps the ODE loop of pass i): same inputs and
     # seed, so the last of them must reproduce the isolated, synchronised warm-up pass bit for bit
-    pipelined_ok = None if isolated_out is None else bool(torch.equal(last_out, isolated_out))
+    pipelined_ok = None
+    if isolated_out is not None and step_frames is None:
+        pipelined_ok = bool(torch.equal(last_out, isolated_out))
     if pipelined_ok is False:
         raise SystemExit("bench: pipelined pass differs from the isolated pass")
     if distributed:
@@ -137,7 +186,14 @@ def main():
 
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     frames = world * args.steps * N_TOTAL * BATCH
-    gen_audio_s = world * args.steps * BATCH * (N_TOTAL - N_REF) * 256 / 24000.0
+    gen_frames = world * args.steps * BATCH * (N_TOTAL - N_REF)
+    if step_frames is not None:   # C4: every rank ran its own utterances
+        tt = torch.tensor([sum(a for a, _ in step_frames[:args.steps]), sum(b for _, b in step_frames[:args.steps])],
+                          device="cuda", dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        frames, gen_frames = int(tt[0].item()), int(tt[1].item())
+    gen_audio_s = gen_frames * 256 / 24000.0
     value = frames / elapsed
 
     roofline = None
@@ -204,20 +260,29 @@ def main():
                                   f"({2 * sample_steps} DiT forwards, {c_loop:.2f} s) + Vocos decode ({c_voc:.2f} s), "
                                   "no warm-up"}
 
+    workload_desc = (f"{args.workload}: F5TTS_v1_Base random-init, batch {BATCH} per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
+                     f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE step, "
+                     "HIP log-mel front-end + Vocos decode on GPU")
+    if args.workload == "C4":
+        workload_desc = ("C4: F5TTS_v1_Base random-init, one utterance per call, lengths from the reference's LibriSpeech-PC "
+                         f"cross-sentence list (750-1875 frames), euler NFE={NFE}, CFG={CFG}, sway={SWAY}, LPT-sharded over "
+                         f"{world} rank(s), hipGraph ODE step, HIP log-mel + Vocos on GPU")
+    if args.workload == "C5":
+        workload_desc = (f"C5: F5TTS_Small + PPG (dim 768, 18 blocks) random-init, batch 1, N_ref={N_REF} N={N_TOTAL} frames, "
+                         f"sample_vc (3 branches batched, alpha_spk 2.5, alpha_ppg 3), euler NFE={NFE}, sway={SWAY}, "
+                         "hipGraph ODE step, HIP log-mel + Vocos on GPU")
     if rank == 0:
         line = {
             "metric": "mel_frames_per_sec", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: F5TTS_v1_Base random-init, batch {BATCH} per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
-                                   f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE step, "
-                                   "HIP log-mel front-end + Vocos decode on GPU",
-                       "frames_per_step": N_TOTAL * BATCH, "parallelism": f"replica x{world} (utterance sharding, no collective "
+            "config": {"workload": workload_desc,
+                       "frames_per_step": (N_TOTAL * BATCH) if step_frames is None else round(frames / (world * args.steps), 1), "parallelism": f"replica x{world} (utterance sharding, no collective "
                                                                   "on the data path)"},
             "rtf": round(elapsed / gen_audio_s, 5),
             "isolated_pass_ms": None if latency_ms is None else round(latency_ms, 2),
             "pipelined_equals_isolated": pipelined_ok,
-            "generated_mel_frames_per_sec": round(world * args.steps * BATCH * (N_TOTAL - N_REF) / elapsed, 2),
+            "generated_mel_frames_per_sec": round(gen_frames / elapsed, 2),
         }
         if roofline is not None:
             line["roofline"] = roofline
