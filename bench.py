@@ -77,6 +77,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torch.distributed.run: always RCCL
     torch.cuda.set_device(local_rank)
+    # host-side prep (seeded noise, masks, token ids) is a few tiny CPU ops per pass: keep every rank on a small, fixed
+    # number of threads so 8 ranks on one node do not oversubscribe the host with OpenMP teams
+    torch.set_num_threads(max(1, min(4, host_threads() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL writes its banner / warnings to stdout: send them to a file so stdout carries exactly one JSON line
