@@ -35,6 +35,7 @@ SIGNATURES = {
     "f5e_rope_table": [_P, _P, _P, _I, _I],
     "f5e_text_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_ode_update": [_P, _P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _P, _LL],
+    "f5e_ode_update_traj": [_P, _P, _LL, _I, _F, _F, _P, _P, _P, _LL, _I, _P, _P, _P, _LL],
     "f5e_advance_eval": [_P, _P],
     "f5e_stitch": [_P, _P, _P, _P, _P, _LL, _I],
     "f5e_cast_bf16": [_P, _P, _P, _LL],

@@ -54,10 +54,15 @@ __global__ void text_gather_kernel(const int* ids, const float* table, const flo
 //   v = mode 0: p0 | mode 1: p0 + (p0 - p1) * w0 | mode 2: w0 (p2 - p1) + w1 (p1 - p0) + p0
 //   dst = base + coef[eval] * v     (+ optional trajectory row)
 __global__ void ode_update_kernel(const float* pred, size_t branch_stride, int mode, float w0, float w1,
-                                  const float* base, float* dst, float* traj, const float* coef, int* eval_ptr,
-                                  unsigned* done_ctr, size_t n) {
-  const int e = eval_ptr ? *eval_ptr : 0;
-  const float h = coef[e];
+                                  const float* base, float* dst, float* traj, size_t traj_stride, int traj_div,
+                                  const float* coef, int* eval_ptr, unsigned* done_ctr, size_t n) {
+  // counter and step size through the scalar cache (both were written by earlier launches): one s_load chain instead of
+  // two dependent vector round trips in front of a 4 us kernel
+  const int e = eval_ptr ? load_uniform_i32(eval_ptr) : 0;
+  const float h = __builtin_bit_cast(float, load_uniform_i32((const int*)(coef + e)));
+  // trajectory row chosen on the device: row (e + 1) / traj_div of [rows][traj_stride] (one captured step serves the
+  // whole grid without a copy launch per step); traj_stride 0 = traj is the row itself
+  if (traj && traj_stride) traj += (size_t)((e + 1) / traj_div) * traj_stride;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float p0 = pred[i];
     float v = p0;
@@ -206,11 +211,18 @@ int f5e_text_gather(hipStream_t st, const int* ids, const float* table, const fl
 int f5e_ode_update(hipStream_t st, const float* pred, long long branch_stride, int mode, float w0, float w1,
                    const float* base, float* dst, float* traj, const float* coef, int* eval_ptr, unsigned* done_ctr,
                    long long n) {
+  return f5e_ode_update_traj(st, pred, branch_stride, mode, w0, w1, base, dst, traj, 0, 1, coef, eval_ptr, done_ctr, n);
+}
+
+int f5e_ode_update_traj(hipStream_t st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+                        const float* base, float* dst, float* traj, long long traj_stride, int traj_div,
+                        const float* coef, int* eval_ptr, unsigned* done_ctr, long long n) {
   F5E_REQUIRE(pred && base && dst && coef && n > 0, "ode_update: bad arguments");
   F5E_REQUIRE(mode >= 0 && mode <= 2, "ode_update: mode must be 0 (plain), 1 (cfg) or 2 (three-branch)");
   F5E_REQUIRE(!done_ctr || eval_ptr, "ode_update: done_ctr (auto-advance) needs eval_ptr");
+  F5E_REQUIRE(traj_stride >= 0 && traj_div >= 1 && (traj_stride == 0 || eval_ptr), "ode_update: bad trajectory indexing");
   hipLaunchKernelGGL(ode_update_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, pred, (size_t)branch_stride, mode,
-                     w0, w1, base, dst, traj, coef, eval_ptr, done_ctr, (size_t)n);
+                     w0, w1, base, dst, traj, (size_t)traj_stride, traj_div, coef, eval_ptr, done_ctr, (size_t)n);
   F5E_LAUNCH_CHECK("ode_update");
   return F5E_OK;
 }

@@ -561,27 +561,27 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         for ev in joins:
             main.wait_event(ev)
 
-    def one_step(traj_row: Optional[Tensor]):
+    def one_step(traj_row: Optional[Tensor], whole_traj: bool = False):
+        # whole_traj: the captured step writes row (eval + 1) // eps_per_step of the trajectory itself
+        kw = dict(traj_stride=n, traj_div=eps_per_step) if whole_traj else {}
         forward_all(plans_a)
         if eps_per_step == 1:
-            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
+            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done, **kw)
         else:
             ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y_mid, coef_d, eval_ptr, None, done)
             forward_all(plans_b)
-            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done)
+            ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done, **kw)
 
     if use_graph and steps > 1:
         ops.Graph.reap()
         gr = ops.Graph()
         gr.begin()
         try:
-            one_step(None)
+            one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
         finally:
             gr.end()
         for i in range(steps):
             gr.launch()
-            if want_trajectory:
-                traj[i + 1].copy_(y)
         gr.retire()   # the launches are still queued: destroy the executable graph only once they have run
     else:
         for i in range(steps):

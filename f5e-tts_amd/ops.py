@@ -276,13 +276,14 @@ def text_gather(ids: Tensor, table: Tensor, pos: Optional[Tensor], keep: Optiona
 
 def ode_update(pred: Tensor, branch_stride: int, mode: int, w0: float, w1: float, base: Tensor, dst: Tensor,
                coef: Tensor, eval_ptr: Optional[Tensor], traj: Optional[Tensor] = None,
-               done_ctr: Optional[Tensor] = None):
-    """done_ctr (int32[1], zero): the kernel itself advances *eval_ptr after every block has read it."""
+               done_ctr: Optional[Tensor] = None, traj_stride: int = 0, traj_div: int = 1):
+    """done_ctr (int32[1], zero): the kernel itself advances *eval_ptr after every block has read it.
+    traj_stride > 0: ``traj`` is the whole [rows, ...] trajectory and row (*eval_ptr + 1) // traj_div gets the copy."""
     require_device()
-    check(lib().f5e_ode_update(_stream(), _p(pred, F32, "pred"), branch_stride, mode, w0, w1, _p(base, F32, "base"),
-                               _p(dst, F32, "dst"), C.c_void_p(traj.data_ptr()) if traj is not None else None,
-                               _p(coef, F32, "coef"), _p(eval_ptr, I32, "eval_ptr"), _p(done_ctr, I32, "done_ctr"),
-                               base.numel()), "f5e_ode_update")
+    check(lib().f5e_ode_update_traj(_stream(), _p(pred, F32, "pred"), branch_stride, mode, w0, w1, _p(base, F32, "base"),
+                                    _p(dst, F32, "dst"), C.c_void_p(traj.data_ptr()) if traj is not None else None,
+                                    traj_stride, traj_div, _p(coef, F32, "coef"), _p(eval_ptr, I32, "eval_ptr"),
+                                    _p(done_ctr, I32, "done_ctr"), base.numel()), "f5e_ode_update")
     return dst
 
 

@@ -167,6 +167,11 @@ int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const flo
 int f5e_ode_update(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
                    const float* base, float* dst, float* traj, const float* coef, int* eval_ptr, unsigned* done_ctr,
                    long long n);
+/* Same, with the trajectory row picked on the device: traj row (*eval_ptr + 1) / traj_div of [rows][traj_stride] floats
+ * (euler: traj_div 1; midpoint's second stage: 2), so a captured step needs no per-step copy.  traj_stride 0 = plain. */
+int f5e_ode_update_traj(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+                        const float* base, float* dst, float* traj, long long traj_stride, int traj_div,
+                        const float* coef, int* eval_ptr, unsigned* done_ctr, long long n);
 int f5e_advance_eval(f5e_stream st, int* eval_ptr);
 /* out = mask ? cond : y   (cfm.py:476); mask u8 [rows], tensors f32 [rows][C] */
 int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
