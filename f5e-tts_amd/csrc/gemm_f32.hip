@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Gemm32Args a) {
   }
 }
 
-// ---- LDS-DMA variant for K % 64 == 0 and no A-side activation (TextEmbedding / Vocos pointwise convs, head) ----
+// ---- LDS-DMA variant for every call without an A-side activation (input projection, TextEmbedding / Vocos convs, head) ----
 // Same ring as gemm_bf16.hip: global_load_lds_dwordx4 into an NSTAGE-deep LDS ring, counted vmcnt + one raw
 // s_barrier per K-step of 64 floats (256-byte rows, 16 chunks of 16 B; chunk ^ (row & 15) on the source address and
 // on the ds_read_b128 -> each 16-lane group covers all 64 banks once).  A lane (fr, fq) reads 4 consecutive k of its
@@ -142,26 +142,33 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
 
   const float* a_src[A_IT];
   const float* w_src[W_IT];
+  int a_k[A_IT], w_k[W_IT];  // first k of the thread's chunk inside a K-tile (for the ragged last tile)
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
     const int i = tid + NT * j, row = i >> 4, c = (i & 15) ^ (row & 15);
     a_src[j] = a.A + (size_t)(min(m0 + row, a.M - 1) % a.a_rows) * a.lda + c * 4;
+    a_k[j] = c * 4;
   }
 #pragma unroll
   for (int j = 0; j < W_IT; ++j) {
     const int i = tid + NT * j, row = i >> 4, c = (i & 15) ^ (row & 15);
     w_src[j] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + c * 4;
+    w_k[j] = c * 4;
   }
   auto dma = [](const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
   };
+  // K % 64 != 0 (K % 4 == 0 always): chunks of the last K-tile that start at k >= K are fetched from the row start
+  // instead (any valid address: no out-of-bounds read) and overwritten with zeros by their owner once they have landed
   auto stage = [&](int buf, int kt) {
     char* base = smem32 + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) dma(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < A_IT; ++j)
+      dma(kt * BK + a_k[j] < a.K ? a_src[j] + kt * BK : a_src[j] - a_k[j], base + (wave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) dma(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < W_IT; ++j)
+      dma(kt * BK + w_k[j] < a.K ? w_src[j] + kt * BK : w_src[j] - w_k[j], base + A_BYTES + (wave * 64 + NT * j) * 16);
   };
 
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int KT = a.K / BK;
+  const int KT = (a.K + BK - 1) / BK;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < KT) stage(s, s);
@@ -183,6 +190,16 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
       case 0: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(0) : "memory"); break;
       case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory"); break;
+    }
+    if (rem == 0 && (a.K & (BK - 1))) {  // ragged tail: own chunks past K become zeros (own DMAs have landed: vmcnt(0))
+      char* base = smem32 + buf * STAGE;
+#pragma unroll
+      for (int j = 0; j < A_IT; ++j)
+        if (kt * BK + a_k[j] >= a.K) *(f32x4*)(base + (tid + NT * j) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < W_IT; ++j)
+        if (kt * BK + w_k[j] >= a.K) *(f32x4*)(base + A_BYTES + (tid + NT * j) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
@@ -271,7 +288,7 @@ extern "C" int f5e_gemm_f32(hipStream_t st, const float* A, int lda, int a_rows,
   a.ch_scale = ch_scale; a.addend = addend; a.ld_add = ld_add; a.add_rows = add_rows > 0 ? add_rows : 1;
   a.row_scale = row_scale; a.out = out; a.ldo = ldo; a.out_bf16 = (bf16*)out_bf16; a.ldo_bf16 = ldo_bf16;
   a.M = M; a.N = N; a.K = K;
-  if (K % 64 == 0 && a_act == F5E_ACT_NONE && (((uintptr_t)A | (uintptr_t)W) & 15) == 0) {
+  if (a_act == F5E_ACT_NONE && (((uintptr_t)A | (uintptr_t)W) & 15) == 0) {  // K % 4 == 0 is checked above
     // few tiles: halve BM so more CUs take part (these GEMMs have M of a few hundred rows)
     if (((M + 63) / 64) * ((N + 63) / 64) < 128) return launch_dma<32, 64, 2, 2, 4>(a, st);
     return launch_dma<64, 64, 2, 2, 3>(a, st);
