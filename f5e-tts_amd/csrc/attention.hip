@@ -38,7 +38,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 template <int NSPLIT>
 __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
   // merge buffers: per extra wave, per lane: 32 O values + m + l
-  __shared__ float red[(NSPLIT > 1 ? NSPLIT - 1 : 1) * 64 * 34];
+  __shared__ __attribute__((aligned(16))) float red[(NSPLIT > 1 ? NSPLIT - 1 : 1) * 64 * 34];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,46 +175,64 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
   }
 
   // ---- merge the NSPLIT partial results (same queries, disjoint keys) ----
+  // red: per extra wave [8 quads][64 lanes] f32x4 (lane-contiguous: conflict-free ds_write/read_b128) + [64 lanes] (m, l)
   if (NSPLIT > 1) {
     if (wave > 0) {
-      float* dst = red + ((wave - 1) * 64 + lane) * 34;
+      f32x4* dq = (f32x4*)(red + (wave - 1) * 64 * 34);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dst[r] = oacc[0][r]; dst[16 + r] = oacc[1][r]; }
-      dst[32] = m_run;
-      dst[33] = l_run;
+      for (int g = 0; g < 4; ++g) {
+        dq[g * 64 + lane] = f32x4{oacc[0][4 * g], oacc[0][4 * g + 1], oacc[0][4 * g + 2], oacc[0][4 * g + 3]};
+        dq[(4 + g) * 64 + lane] = f32x4{oacc[1][4 * g], oacc[1][4 * g + 1], oacc[1][4 * g + 2], oacc[1][4 * g + 3]};
+      }
+      *(f32x2*)(red + (wave - 1) * 64 * 34 + 64 * 32 + lane * 2) = f32x2{m_run, l_run};
     }
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
     for (int w = 1; w < NSPLIT; ++w) {
-      const float* src = red + ((w - 1) * 64 + lane) * 34;
-      const float m_o = src[32], l_o = src[33];
-      const float m_new = fmaxf(m_run, m_o);
+      const f32x4* sq = (const f32x4*)(red + (w - 1) * 64 * 34);
+      const f32x2 ml = *(const f32x2*)(red + (w - 1) * 64 * 34 + 64 * 32 + lane * 2);
+      const float m_new = fmaxf(m_run, ml[0]);
       // a wave that saw no tile has m = -inf, l = 0, O = 0: its factor is exp2(-inf) = 0 (m_new is finite because
       // wave 0 always owns tile 0 when kv_len > 0)
-      const float fa = fast_exp2(m_run - m_new), fb = fast_exp2(m_o - m_new);
+      const float fa = fast_exp2(m_run - m_new), fb = fast_exp2(ml[0] - m_new);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        oacc[0][r] = oacc[0][r] * fa + src[r] * fb;
-        oacc[1][r] = oacc[1][r] * fa + src[16 + r] * fb;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 s0 = sq[g * 64 + lane], s1 = sq[(4 + g) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          oacc[0][4 * g + r] = oacc[0][4 * g + r] * fa + s0[r] * fb;
+          oacc[1][4 * g + r] = oacc[1][4 * g + r] * fa + s1[r] * fb;
+        }
       }
-      l_run = l_run * fa + l_o * fb;
+      l_run = l_run * fa + ml[1] * fb;
       m_run = m_new;
     }
   }
 
   // ---- normalise + store: oacc[dt][reg] = O[q = ql][d = 32 dt + (reg&3) + 8 (reg>>2) + 4 hh] ----
-  const int q_row = qt * 32 + ql;
-  if (q_row < a.rows_per_seq) {
+  // From the accumulator layout a store instruction would write 8-byte pieces of 32 different rows.  The 32 x 64 bf16 tile
+  // is turned row-major in LDS (144-byte rows; `red` is free: the merge reads above are this wave's own, in order) and
+  // leaves as 4 instructions of 8 full 128-byte row segments each.
+  {
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16* op = a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + 4 * hh;
+    char* stg = (char*)red;
+    if (NSPLIT > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *(bf16x4*)(op + dt * 32 + 8 * g) = f2bf4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv,
-                                                   oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
-      }
+      for (int g = 0; g < 4; ++g)
+        *(bf16x4*)(stg + ql * 144 + 64 * dt + 16 * g + 8 * hh) =
+            f2bf4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + (lane >> 3), c = lane & 7;
+      const int q_row = qt * 32 + r;
+      const uint4 v = *(const uint4*)(stg + r * 144 + c * 16);
+      if (q_row < a.rows_per_seq)
+        *(uint4*)(a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + c * 8) = v;
+    }
   }
 }
 
@@ -375,7 +393,7 @@ extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, cons
   F5E_REQUIRE(S > 0 && H > 0 && rows_per_seq > 0, "flash_attn: empty problem");
   F5E_REQUIRE(n_pad % 64 == 0 && n_pad >= rows_per_seq, "flash_attn: n_pad=%d must be a multiple of 64 and >= %d",
               n_pad, rows_per_seq);
-  F5E_REQUIRE(ldo % 4 == 0 && ldo >= H * 64, "flash_attn: bad ldo=%d", ldo);
+  F5E_REQUIRE(ldo % 8 == 0 && ldo >= H * 64 && ((uintptr_t)o & 15) == 0, "flash_attn: bad ldo=%d / output alignment", ldo);
   AttnArgs a{};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o; a.ldo = ldo;
   a.kv_len = kv_len; a.S = S; a.H = H; a.rows_per_seq = rows_per_seq; a.n_pad = n_pad;
