@@ -482,6 +482,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     B, N, mel = inp.y0.shape
     nb = len(inp.branches)
     S = nb * B
+    caller_setup = setup is not None
     if setup is None:
         setup = ode_setup(engine, inp)
     steps, eps_per_step, mod, cd = setup["steps"], setup["eps_per_step"], setup["mod"], setup["cd"]
@@ -582,7 +583,13 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             gr.end()
         for i in range(steps):
             gr.launch()
-        gr.retire()   # the launches are still queued: destroy the executable graph only once they have run
+        # the launches are still queued: the executable graph may only be destroyed once they have run.  The event that
+        # guards it must NOT live on this (capture) stream -- another thread polling it while this stream is capturing
+        # again invalidates that capture -- so a caller that owns the stream choreography retires it on its own stream
+        if caller_setup:
+            setup["graph"] = gr
+        else:
+            gr.retire()
     else:
         for i in range(steps):
             one_step(traj[i + 1] if want_trajectory else None)

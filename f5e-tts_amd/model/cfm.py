@@ -145,6 +145,8 @@ class CFM(nn.Module):
             with torch.cuda.stream(side):
                 trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup)
             cur.wait_stream(side)
+            if setup.get("graph") is not None:
+                setup.pop("graph").retire()   # event on the caller's stream (behind the wait): safe to poll from any thread
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)
         self.transformer.clear_cache()
