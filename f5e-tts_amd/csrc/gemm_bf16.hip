@@ -479,8 +479,10 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
     }
   }
-  // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip); hint 9 forces it (tests / tuning)
-  if (sel == 9 || (tile_hint == 0 && a.K >= 128 && blocks(256, 256) >= 512)) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
+  // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip); hint 9 forces it (tests / tuning).  Crossover against the
+  // 128x128 ring kernel measured on the four DiT shapes (tools/gemm_tune.py M 21,9): M = 7.5k ring kernel ahead by 0-40 %,
+  // M = 13k ping-pong ahead by 5-18 %, M = 30k by 8-37 %: it takes over at 44 row tiles of 256, whatever N.
+  if (sel == 9 || (tile_hint == 0 && a.K >= 128 && (a.M + 255) / 256 >= 44)) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and

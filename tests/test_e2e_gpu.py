@@ -55,7 +55,7 @@ def test_dit_sample_single_forward(B, N, masked):
 
 
 def test_large_batch_forward_takes_the_pingpong_gemm():
-    """B = 14 x N = 938 rows (13 132 >= the 256x256-tile threshold for the QKV and FF1 linears): the ping-pong GEMM kernel
+    """B = 14 x N = 938 rows (13 132 >= the 256x256-tile threshold of 44 row tiles): the ping-pong GEMM kernel
     (gemm_bf16_pp.hip) is selected automatically; masked batch, against the fp32 oracle."""
     cfg = O.DiTConfig(**dict(SMALL, depth=1))
     sd, dit, _ = build(cfg)
