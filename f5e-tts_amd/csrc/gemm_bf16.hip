@@ -487,7 +487,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
     // tools/gemm_tune.py on MI355X has 64x64 / 3 stages fastest for every DiT shape at M = 938
-    if (blocks(128, 128) >= 512) sel = 1;
+    if (blocks(128, 128) >= 320) sel = 1;  // 8-wave 128x128: ahead of the smaller tiles from ~1.3 workgroups per CU on
     else if (blocks(128, 64) >= 512) sel = 2;
     else sel = 3;
   }
