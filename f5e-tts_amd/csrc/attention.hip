@@ -128,17 +128,21 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
     // maximum is only moved -- with the 32-multiply rescale of the accumulators -- when some query of the wave gained more
     // than 2^8 on it: p <= 256 keeps fp32 sums and the bf16 P operand as accurate as before, and (m, l, O) stay
     // consistent, so the final O / l is unchanged mathematically.
+    if (partial) {
+      // only the last tile of a sequence: a real branch (the empty asm keeps hipcc from if-converting the block into 32
+      // compares + 32 selects executed on EVERY tile)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key_base + t * 32 + (r & 3) + 8 * (r >> 2) >= kv_len) st[t][r] = -INFINITY;
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (partial) {
-          const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= kv_len) st[t][r] = -INFINITY;
-        }
-        mx = fmaxf(mx, st[t][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
     mx = max_xor32(mx) * a.scale_log2e;           // finite: every processed tile holds at least one valid key
     const bool jump = mx - m_run > 8.0f;          // first tile: m_run = -inf
     if (__builtin_amdgcn_ballot_w64(jump) != 0) {
@@ -322,17 +326,21 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
     const int key_base = t64 * 64 + 4 * hh;
     const bool partial = (t64 * 64 + 64 > kv_len);
     // same softmax as attn_fwd_kernel: raw maximum, scale folded into the fma, running maximum moved lazily (> 2^8)
+    if (partial) {
+      // only the last tile of a sequence: a real branch (the empty asm keeps hipcc from if-converting the block into 32
+      // compares + 32 selects executed on EVERY tile)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key_base + t * 32 + (r & 3) + 8 * (r >> 2) >= kv_len) st[t][r] = -INFINITY;
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (partial) {
-          const int key = key_base + t * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= kv_len) st[t][r] = -INFINITY;
-        }
-        mx = fmaxf(mx, st[t][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
     mx = max_xor32(mx) * a.scale_log2e;
     const bool jump = mx - m_run > 8.0f;
     if (__builtin_amdgcn_ballot_w64(jump) != 0) {
