@@ -279,6 +279,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     }
   }
 
+  int qkv_which = 0, qkv_head = 0, qkv_d0 = 0;
+  bf16* qkv_base = nullptr;
+  size_t qkv_seq_stride = 0;
+  if (EPI == EPI_QKV_ROPE) {
+    static_assert(EPI != EPI_QKV_ROPE || WN <= 64, "a wave's columns must stay inside one 64-wide head");
+    const int inner = a.heads * 64, hb = n0 + wn0;   // hb: multiple of WN, wave-uniform
+    qkv_which = hb / inner;
+    qkv_head = (hb - qkv_which * inner) >> 6;
+    qkv_d0 = hb & 63;
+    qkv_seq_stride = (size_t)a.heads * a.n_pad * 64;
+    qkv_base = (qkv_which == 0 ? a.q : (qkv_which == 1 ? a.k : a.vt)) + (size_t)qkv_head * a.n_pad * 64;
+  }
+
   // ---- epilogue: acc[i][j][r] = C[m = m0+wm0+16j+fr][n = n0+wn0+16i+4fq+r] ----
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -358,31 +371,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
           *(f32x4*)xp = x;
         }
       } else if (EPI == EPI_QKV_ROPE) {
-        const int inner = a.heads * 64;
-        const int which = n / inner;
-        const int nn = n - which * inner;
-        const int head = nn >> 6, d = nn & 63;
+        // fragment-major layouts consumed by attention.hip (index maps documented there).  A wave's columns lie inside
+        // ONE head (WN <= 64, aligned), so q / k / v and the head are wave-uniform scalars and every offset is
+        // (row part: sequence, position) + (column part: head, d) -- no division or 64-bit chain per quad.
+        const int d = qkv_d0 + i * 16 + fq * 4;
         if (qk_w) v = v * qk_rn * *(const f32x4*)(qk_w + d);
-        if (which < 2 && head < a.rope_heads) {
-          const f32x4 cs = *(const f32x4*)(a.cos_sin + ((size_t)pos * 32 + (d >> 1)) * 2);
-          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-          v[0] = x0 * cs[0] - x1 * cs[1];
-          v[1] = x1 * cs[0] + x0 * cs[1];
-          v[2] = x2 * cs[2] - x3 * cs[3];
-          v[3] = x3 * cs[2] + x2 * cs[3];
-        }
-        const size_t sh = (size_t)seq * a.heads + head;
-        // fragment-major layouts consumed by attention.hip (index maps documented there)
-        const int tile = pos >> 5, pr = pos & 31;
-        if (which < 2) {
-          bf16* dst = (which == 0 ? a.q : a.k) + sh * a.n_pad * 64 +
-                      ((size_t)(tile * 4 + (d >> 4)) * 32 + pr) * 16 + ((d >> 3) & 1) * 8 + (d & 7);
-          *(bf16x4*)dst = f2bf4(v[0], v[1], v[2], v[3]);
+        if (qkv_which < 2) {
+          if (qkv_head < a.rope_heads) {
+            const f32x4 cs = *(const f32x4*)(a.cos_sin + (size_t)pos * 64 + d);   // [(d >> 1)][2] floats
+            const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+            v[0] = x0 * cs[0] - x1 * cs[1];
+            v[1] = x1 * cs[0] + x0 * cs[1];
+            v[2] = x2 * cs[2] - x3 * cs[3];
+            v[3] = x3 * cs[2] + x2 * cs[3];
+          }
+          // [tile = pos/32][ks = d/16][pos%32][(d/8)%2][d%8]
+          const int off = (pos >> 5) * 2048 + (pos & 31) * 16 + (d >> 4) * 512 + ((d >> 3) & 1) * 8 + (d & 7);
+          *(bf16x4*)(qkv_base + (size_t)seq * qkv_seq_stride + off) = f2bf4(v[0], v[1], v[2], v[3]);
         } else {
-          const int s16 = pr >> 4, k16 = pr & 15;
-          const int jj = ((k16 >> 3) << 2) | (k16 & 3), hk = (k16 >> 2) & 1;
-          bf16* dst = a.vt + sh * a.n_pad * 64 +
-                      ((((size_t)(tile * 2 + s16) * 2 + (d >> 5)) * 32 + (d & 31)) * 2 + hk) * 8 + jj;
+          // [group = pos/16][dt = d/32][d%32][h][j], pos%16 = 8 (j>>2) + 4 h + (j&3)
+          const int k16 = pos & 15;
+          const int off = (pos >> 4) * 1024 + (d >> 5) * 512 + (d & 31) * 16 + ((k16 >> 2) & 1) * 8 + (((k16 >> 3) << 2) | (k16 & 3));
+          bf16* dst = qkv_base + (size_t)seq * qkv_seq_stride + off;
           dst[0] = (bf16)v[0];
           dst[16] = (bf16)v[1];
           dst[32] = (bf16)v[2];
@@ -503,9 +513,6 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     case 42: return launch<128, 128, EPI, 2, 2, 2>(a, st);   // 4 waves, 64 x 64 per wave (tuning reference)
     case 83: return launch<128, 128, EPI, 3, 4, 2>(a, st);   // experiments: deeper rings / bigger tiles, 1 workgroup per CU
     case 84: return launch<128, 128, EPI, 4, 4, 2>(a, st);
-    case 53: return launch<256, 128, EPI, 3, 4, 2>(a, st);
-    case 62: return launch<256, 256, EPI, 2, 4, 2>(a, st);
-    case 72: return launch<256, 256, EPI, 2, 2, 4>(a, st);
     case 13: return launch<128, 128, EPI, 3>(a, st);
     case 22: return launch<128, 64, EPI, 2>(a, st);
     case 23: return launch<128, 64, EPI, 3>(a, st);
