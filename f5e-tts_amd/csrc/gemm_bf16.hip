@@ -60,6 +60,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     if (tid == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[1] = __builtin_amdgcn_s_memtime(); }
   }
 
+  // Kernarg lines beyond the first: request them NOW, next to the first line, so their (cold) scalar-cache misses overlap
+  // instead of surfacing one by one where the compiler first needs a field (the prefetch block behind the prologue).
+  if (FUSE == 1)
+    asm volatile("" ::"s"(a.ln_stats), "s"(a.ln_c), "s"(a.ln_d), "s"(a.ln_parts), "s"(a.cd_stride), "s"(a.cd_rows),
+                 "s"(a.cd_eval_stride), "s"(a.eval_ptr));
+  if (EPI == EPI_GATE_RES)
+    asm volatile("" ::"s"(a.resid), "s"(a.gate), "s"(a.seq_len), "s"(a.eval_ptr), "s"(a.ldr), "s"(a.gate_stride),
+                 "s"(a.gate_rows), "s"(a.eval_stride), "s"(a.bias));
+  if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs));
+  if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
+
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
   int bid = blockIdx.x;
   {
@@ -72,10 +83,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   // (small batch), the activation panel when M > N (large batch: otherwise A is re-fetched once per n-panel)
   int tile_m, tile_n;
   if (a.m_major) {
-    tile_m = bid / a.tiles_n;
+    tile_m = div_magic(bid, a.tiles_n, a.tile_magic);
     tile_n = bid - tile_m * a.tiles_n;
   } else {
-    tile_n = bid / a.tiles_m;
+    tile_n = div_magic(bid, a.tiles_m, a.tile_magic);
     tile_m = bid - tile_n * a.tiles_m;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -135,15 +146,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   // vector loads between the prologue's LDS-DMAs and the first counted wait (run by `make check`).  `volatile` is no
   // way to pin them: hipcc turns volatile loads into flat_load sc0 sc1 + s_waitcnt vmcnt(0) each.
   asm volatile("" ::: "memory");
+  if constexpr (DBG == 3) { if (tid == 0) trc[46] = __builtin_amdgcn_s_memtime(); }
   constexpr bool PREF = (TM * TN <= 4);
   static_assert(FUSE == 0 || (PREF && BM == 64 && BN == 64 && WGM == 2 && WGN == 2), "fused AdaLN: 64x64 tiles only");
   static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
-  constexpr int NPC = FUSE == 1 ? 2 * TM * TN + 8 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0));
+  constexpr int NPC = FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0));
   static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
   f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
-  f32x4 pf_c[FUSE == 1 ? TN : 1][FUSE == 1 ? TM : 1], pf_d[FUSE == 1 ? TN : 1][FUSE == 1 ? TM : 1];
+  f32x4 pf_c[FUSE == 1 ? TN : 1], pf_d[FUSE == 1 ? TN : 1];
   f32x4 pf_ns[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
-  f32x2 pf_st[FUSE == 1 ? 8 : 1];
+  f32x2 pf_st[FUSE == 1 ? 4 : 1];
   bool pf_live[PREF ? TM : 1];
   int pf_len[PREF ? TM : 1];
   auto ldv4 = [](const float* ptr) -> f32x4 { return *(const f32x4*)ptr; };
@@ -153,11 +165,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm0 + j * 16 + fr, mc = min(m, a.M - 1);
-        const int seq = mc / a.rows_per_seq;
+        const int seq = div_magic(mc, a.rows_per_seq, a.rps_magic);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
-          const size_t goff = eoff + (size_t)(seq % a.gate_rows) * a.gate_stride + nc;
+          const size_t goff = eoff + (a.gate_rows == 1 ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
           pf_gate[i][j] = ldv4(a.gate + goff);                       // counted
           pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);      // counted
           if (FUSE == 2) pf_ns[i][j] = ldv4(a.next_scale + goff);    // counted
@@ -166,27 +178,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     }
   }
   if (FUSE == 1) {
+    // As few vector-memory instructions as possible: the CU's address unit takes ~16 cycles per wave-instruction whatever
+    // its width, and all 12 waves of a CU run this block at once (tools/gemm_trace.hip: 16 extra loads per wave cost 2100
+    // cycles before the first K-step).  One table row per evaluation (cd_rows == 1, checked on the host): c and d do not
+    // depend on the row -> 2 TN loads; statistics: 4 threads per row, ln_parts / 4 <= 4 consecutive (mean, M2) pairs each
+    // (the 64 lanes of a wave read one contiguous range of [M][parts][2]); entries past a thread's share repeat its last.
     const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+    const float* cbase = a.ln_c + eoff;
+    const float* dbase = a.ln_d + eoff;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
-      const size_t roff = eoff + (size_t)((mc / a.rows_per_seq) % a.cd_rows) * a.cd_stride;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
-        pf_c[i][j] = ldv4(a.ln_c + roff + nc);                       // counted
-        pf_d[i][j] = ldv4(a.ln_d + roff + nc);                       // counted
-      }
+    for (int i = 0; i < TN; ++i) {
+      const unsigned nc = (unsigned)min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
+      pf_c[i] = ldv4(cbase + nc);                                    // counted
+      pf_d[i] = ldv4(dbase + nc);                                    // counted
     }
-    // row statistics: 4 threads per row of the tile, each takes ln_parts / 4 CONSECUTIVE 64-column partials (<= 8), so
-    // the 64 lanes of a wave read one contiguous range of [M][parts][2] instead of 16 strided rows per instruction
-    // (ln_parts % 4 == 0: D is a multiple of 256).  Entries past the thread's share repeat its last one (not summed).
     const int pp = a.ln_parts >> 2;
-    const long long last = (long long)a.M * a.ln_parts - 1;
+    const float* sbase = a.ln_stats + (size_t)m0 * a.ln_parts * 2;          // uniform
+    const unsigned rel_max = (unsigned)((a.M - m0) * a.ln_parts - 1);       // last valid pair of the tile's rows
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long e = (long long)m0 * a.ln_parts + tid * pp + min(u, pp - 1);
-      pf_st[u] = *(const f32x2*)(a.ln_stats + (size_t)(e < last ? e : last) * 2);  // counted
+    for (int u = 0; u < 4; ++u) {
+      const unsigned rel = min((unsigned)(tid * pp + min(u, pp - 1)), rel_max);
+      pf_st[u] = *(const f32x2*)(sbase + rel * 2u);                  // counted
     }
   }
   if (PREF) {  // not counted: may be skipped
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
-        pf_len[j] = a.seq_len ? a.seq_len[mc / a.rows_per_seq] : a.rows_per_seq;
+        pf_len[j] = a.seq_len ? a.seq_len[div_magic(mc, a.rows_per_seq, a.rps_magic)] : a.rows_per_seq;
       }
     }
   }
@@ -250,14 +262,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     const int sq = tid & 3, pp = a.ln_parts >> 2;
     float sm = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 4; ++u)
       if (u < pp) sm += pf_st[u][0];
     sm = add_xor2(add_xor1(sm));
     const float mean = sm / (float)a.ln_parts;
     const float cols = (float)(a.K / a.ln_parts);
     float m2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 4; ++u)
       if (u < pp) {
         const float dm = pf_st[u][0] - mean;
         m2 += pf_st[u][1] + cols * dm * dm;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m0 + wm0 + j * 16 + fr;
-      pf_live[j] = (m < a.M) && (m % a.rows_per_seq < pf_len[j]);
+      pf_live[j] = (m < a.M) && (m - div_magic(m, a.rows_per_seq, a.rps_magic) * a.rows_per_seq < pf_len[j]);
     }
   }
 
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     }
     int seq = 0, pos = m;
     if (EPI == EPI_GATE_RES || EPI == EPI_QKV_ROPE) {
-      seq = m / a.rows_per_seq;
+      seq = div_magic(m, a.rows_per_seq, a.rps_magic);
       pos = m - seq * a.rows_per_seq;
     }
     // optional qk RMSNorm (reference modules.py:464-467 + :275-294): needs a whole head (64 columns) in one wave,
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
       if (FUSE == 1) {
-        v = ln_rstd * (v - ln_mean * pf_c[i][j]) + pf_d[i][j];  // d carries the bias
+        v = ln_rstd * (v - ln_mean * pf_c[i]) + pf_d[i];  // d carries the bias
       } else if (PREF) {
         v += pf_bias[i];
       } else if (a.bias) {
@@ -448,6 +460,8 @@ int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.m_major = a.M > a.N;
+  a.tile_magic = div_magic_of(a.m_major ? a.tiles_n : a.tiles_m);
+  a.rps_magic = div_magic_of(a.rows_per_seq);
   const int grid = a.tiles_m * a.tiles_n;
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2 + (FUSE ? 1024 : 0);
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
@@ -466,6 +480,8 @@ int launch_dbg(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 63) / 64;
   a.tiles_n = (a.N + 63) / 64;
   a.m_major = 0;
+  a.tile_magic = div_magic_of(a.tiles_m);
+  a.rps_magic = div_magic_of(a.rows_per_seq);
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, EPI, 3, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), 3 * 128 * 128, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_dbg");
   return F5E_OK;
@@ -543,9 +559,10 @@ int check_common(const GemmArgs& a) {
 int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
   if (!ln || !ln->stats) return F5E_OK;
   F5E_REQUIRE(bias == nullptr, "gemm_bf16: with fused AdaLN the bias is part of the d table");
-  F5E_REQUIRE(ln->c && ln->d && ln->parts > 0 && ln->parts <= 32 && ln->parts % 4 == 0 && a.K % ln->parts == 0 && ln->cd_rows > 0 &&
+  F5E_REQUIRE(ln->c && ln->d && ln->parts > 0 && ln->parts <= 16 && ln->parts % 4 == 0 && ln->cd_rows == 1 && a.K % ln->parts == 0 && ln->cd_rows > 0 &&
                   ln->cd_stride % 4 == 0 && ln->cd_eval_stride % 4 == 0 && ln->rows_per_seq > 0,
-              "gemm_bf16: bad fused-AdaLN consumer arguments (parts=%d)", ln->parts);
+              "gemm_bf16: bad fused-AdaLN consumer arguments (parts=%d: a multiple of 4 up to 16; one table row per evaluation)",
+              ln->parts);
   a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;
   a.cd_rows = ln->cd_rows; a.cd_eval_stride = ln->cd_eval_stride; a.ln_eps = ln->eps;
   a.eval_ptr = ln->eval_ptr;

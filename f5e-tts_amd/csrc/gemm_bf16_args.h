@@ -1,28 +1,38 @@
 // Argument block, epilogue ids and the LDS-DMA helper shared by the bf16 GEMM kernels (gemm_bf16.hip: 64x64 .. 128x128
 // ring kernels; gemm_bf16_pp.hip: the 256x256 ping-pong kernel for large M).  Internal to the library (not ABI).
 #pragma once
+#include <cstddef>
+
 #include "f5e_common.h"
 
 namespace f5e_gemm {
 
 struct GemmArgs {
-  const bf16* A; int lda;
-  const bf16* W; int ldw;
-  const float* bias;
+  // First 64 bytes = everything a workgroup needs before it can issue its first LDS-DMA: ONE scalar-cache line, fetched by
+  // the first s_loads of the kernel.  (Measured with tools/gemm_trace.hip: 2500 cycles from kernel entry to the first
+  // DMA when these fields were spread over three kernarg lines with two integer divisions in between; the kernarg
+  // segment is cold in every launch.)
+  const bf16* A; const bf16* W;
+  int lda, ldw;
   int M, N, K;
+  int tiles_m, tiles_n, m_major;
+  unsigned tile_magic;   // floor(2^32 / (m_major ? tiles_n : tiles_m)): tile decode without a division (div_magic)
+  int rows_per_seq;
+  unsigned rps_magic;    // floor(2^32 / rows_per_seq)
+  int pad0_;
+  // ---- epilogue operands ----
+  const float* bias;
   void* out; int ldo;
   // gate + residual epilogue
   float* resid; int ldr;
   const float* gate; int gate_stride; int gate_rows;
   const int* eval_ptr; int eval_stride;
-  int rows_per_seq;
   const int* seq_len;
   // qkv + rope epilogue
   bf16* q; bf16* k; bf16* vt;
   int n_pad; int heads; int rope_heads;
   const float* cos_sin;  // [rows_per_seq][32][2]
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
-  int tiles_m, tiles_n, m_major;
   unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
   // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
   //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
@@ -34,6 +44,20 @@ struct GemmArgs {
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
   int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
 };
+
+static_assert(offsetof(GemmArgs, pad0_) + sizeof(int) == 64, "hot kernarg fields must fill exactly the first 64-byte line");
+
+// floor(n / d) for 0 <= n < 2^31, d >= 1, magic = min(floor(2^32 / d), 2^32 - 1): one mul_hi + one correction step
+// (s_mul_hi_u32 on uniform operands) instead of the ~40-instruction reciprocal sequence hipcc emits for `/`.
+__host__ __device__ inline unsigned div_magic_of(int d) {
+  const unsigned long long m = 0x100000000ull / (unsigned long long)(d > 0 ? d : 1);
+  return m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)m;
+}
+__device__ __forceinline__ int div_magic(int n, int d, unsigned magic) {
+  unsigned q = __umulhi((unsigned)n, magic);
+  if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+  return (int)q;
+}
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
 

@@ -165,8 +165,8 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     // Fused AdaLN chain (f5e_ln_fuse): hn holds xs = bf16(x (1 + scale)) for the next linear, ln_stats the tile
     // statistics of x; every gate+residual GEMM refreshes both for the norm that follows it.
     F5E_REQUIRE(!p->w_skip, "dit_forward: fused AdaLN does not cover the long skip connection");
-    F5E_REQUIRE(p->ln_stats && p->cd && D % 64 == 0 && D / 64 <= 32 && inner == D && p->cd_stride % 4 == 0,
-                "dit_forward: fused AdaLN needs ln_stats, cd tables, D %% 64 == 0, D <= 2048 and heads * 64 == D");
+    F5E_REQUIRE(p->ln_stats && p->cd && D % 256 == 0 && D <= 1024 && p->mod_rows == 1 && inner == D && p->cd_stride % 4 == 0,
+                "dit_forward: fused AdaLN needs ln_stats, cd tables, D %% 256 == 0, D <= 1024, one modulation row and heads * 64 == D");
     const int parts = D / 64, ls = 6 * inner + 2 * p->FF, cd_eval_stride = p->mod_rows * p->cd_stride;
     F5E_REQUIRE(p->cd_stride >= p->L * ls + 2 * p->mel, "dit_forward: cd_stride too small");
     f5e_ln_fuse cons{}, prod{};

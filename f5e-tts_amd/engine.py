@@ -179,7 +179,7 @@ class DiTEngine:
     @property
     def can_fuse_ln(self) -> bool:
         cfg = self.cfg
-        return (cfg.qk_norm is None and not cfg.long_skip_connection and cfg.dim % 64 == 0 and cfg.dim <= 2048
+        return (cfg.qk_norm is None and not cfg.long_skip_connection and cfg.dim % 256 == 0 and cfg.dim <= 1024
                 and self.inner == cfg.dim)
 
     def cd_tables(self, mod: Tensor) -> Tensor:
@@ -368,7 +368,7 @@ class DiTEngine:
             p.w_skip = self.skip_w.data_ptr()
         for k, t in ws.items():
             setattr(p, k, t.data_ptr())
-        if cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS:
+        if cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS and cd.shape[1] == 1:
             ws["ln_stats"] = torch.empty(M, D // 64, 2, device=dv)
             p.fuse_ln, p.ln_stats, p.cd, p.cd_stride = 1, ws["ln_stats"].data_ptr(), cd.data_ptr(), cd.shape[2]
         return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len, cd))

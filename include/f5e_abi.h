@@ -75,7 +75,8 @@ int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W,
  *     tables c[n] = sum_k W[n][k] (1 + scale[k]),  d[n] = sum_k W[n][k] shift[k] + bias[n]  (row r =
  *     (m / rows_per_seq) % cd_rows, advanced by (*eval_ptr) * cd_eval_stride), mean / rstd combined from the
  *     `parts` tile statistics (Chan's formula, fixed order); pass bias = NULL to the GEMM.
- * Only one side is used per launch; leave the other side's pointers NULL.  64x64 tiles (the small-M tile). */
+ * Only one side is used per launch; leave the other side's pointers NULL.  64x64 tiles (the small-M tile).
+ * Consumer limits: parts a multiple of 4 up to 16 (D <= 1024), cd_rows == 1 (one table row per evaluation). */
 typedef struct f5e_ln_fuse {
   const float* stats; int parts;                       /* consumer */
   const float* c; const float* d; int cd_stride; int cd_rows; int cd_eval_stride;

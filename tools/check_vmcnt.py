@@ -85,7 +85,7 @@ for key, ins in sorted(body.items()):
     BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE = key
     TM, TN = BM // WGM // 16, BN // WGN // 16
     pref = TM * TN <= 4
-    npc = 2 * TM * TN + 8 if FUSE == 1 else 3 * TM * TN if FUSE == 2 else (2 * TM * TN if (pref and EPI == 2) else 0)
+    npc = 2 * TN + 4 if FUSE == 1 else 3 * TM * TN if FUSE == 2 else (2 * TM * TN if (pref and EPI == 2) else 0)
     if npc == 0:
         continue
     first_barrier = next(i for i, t in enumerate(ins) if t.startswith("s_barrier"))

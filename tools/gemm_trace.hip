@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> h((size_t)L * max_grid * 48);
   hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost);
   const int KT = K / 64;
-  std::vector<double> gap, ramp, span, first, iter, loop, epil, wg_total, clk;
+  std::vector<double> gap, ramp, span, first, iter, loop, epil, wg_total, clk, issue, dmaissue;
   for (int l = 12; l < L; ++l) {
     auto T = [&](int wg, int slot) { return h[((size_t)l * max_grid + wg) * 48 + slot]; };
     auto P = [&](int wg, int slot) { return h[((size_t)(l - 1) * max_grid + wg) * 48 + slot]; };
@@ -110,6 +110,8 @@ int main(int argc, char** argv) {
       s_min = std::min(s_min, T(w, 0)); s_max = std::max(s_max, T(w, 0)); e_max = std::max(e_max, T(w, 41));
       pe_max = std::max(pe_max, P(w, 41));
       first.push_back((double)(T(w, 4) - T(w, 1)));
+      issue.push_back((double)(T(w, 2) - T(w, 1)));
+      dmaissue.push_back((double)(T(w, 46) - T(w, 1)));
       iter.push_back((double)(T(w, 4 + std::min(KT, 36) - 1) - T(w, 4)) / (std::min(KT, 36) - 1));
       loop.push_back((double)(T(w, 3) - T(w, 4)));
       epil.push_back((double)(T(w, 40) - T(w, 3)));
@@ -125,8 +127,8 @@ int main(int argc, char** argv) {
   printf("variant %d tile %dx%d M=%d N=%d K=%d epi=%d grid=%d  shader clock ~%.0f MHz\n", variant, bm, bn, M, N, K, epi, grid, mhz);
   printf("  per launch [ns]: gap after previous kernel's last end -> first start %.0f | start ramp (first->last workgroup) %.0f | span first start -> last end %.0f\n",
          med(gap), med(ramp), med(span));
-  printf("  per workgroup [cycles, median]: entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
-         med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
+  printf("  per workgroup [cycles, median]: entry->prologue DMAs issued %.0f | +prefetch issued %.0f | entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
+         med(dmaissue), med(issue), med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
   if (variant == 10) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
     std::vector<double> a42, a43, a44, a45, a40;
     const int l = L - 1;
