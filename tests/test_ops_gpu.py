@@ -242,7 +242,9 @@ def test_gemm_f32(ops, M, N, K):
 
 
 @pytest.mark.parametrize("S,N,D,G", [(2, 469, 1024, 16), (3, 70, 128, 2), (1, 5, 64, 1), (2, 100, 768, 16),
-                                     (1, 130, 256, 16), (2, 65, 512, 16)])
+                                     (1, 130, 256, 16), (2, 65, 512, 16),
+                                     # more workgroups than CUs: the output-split ring kernel (the others: split-tap)
+                                     (8, 300, 1024, 16), (40, 130, 256, 16), (30, 64, 384, 8)])
 def test_convpos(ops, S, N, D, G):
     cpg = D // G
     x = torch.randn(S, N, D, generator=g(31)).to(BF)
