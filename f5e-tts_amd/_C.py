@@ -29,6 +29,7 @@ SIGNATURES = {
     "f5e_l2norm": [_P, _P, _I, _P, _I, _I, _P, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
+    "f5e_convpos_ln": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
     "f5e_sinus_embed": [_P, _P, _P, _P, _I, _I, _F],

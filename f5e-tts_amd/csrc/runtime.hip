@@ -154,7 +154,10 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
                        p->in_const, D, M, nullptr, p->h0, D, p->h0_bf16, D, M, D, p->mel));
   // K5: conv position embedding + residual (dit.py:176)
   F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D, p->convpos_groups));
-  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D, p->convpos_groups));
+  // with the fused-AdaLN chain (and no long skip) the second conv also writes the chain's head (xs, statistics)
+  const bool head_in_conv = p->fuse_ln && !p->w_skip;
+  if (!head_in_conv)
+    F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D, p->convpos_groups));
 
   if (p->w_skip) {  // long skip connection keeps the embedded input (backbones/dit.py:456-457)
     F5E_REQUIRE(p->skip_res && p->skip_tmp, "dit_forward: long skip needs skip_res / skip_tmp");
@@ -173,8 +176,9 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     cons.stats = p->ln_stats; cons.parts = parts; cons.cd_stride = p->cd_stride; cons.cd_rows = p->mod_rows;
     cons.cd_eval_stride = cd_eval_stride; cons.eval_ptr = p->eval_ptr; cons.rows_per_seq = p->N; cons.eps = 1e-6f;
     prod.xs_out = p->hn; prod.ld_xs = D; prod.stats_out = p->ln_stats;
-    F5E_TIMED(F5E_OP_LN, f5e_adaln_pre(st, p->x, D, p->hn, D, p->mod + D, row_stride, p->mod_rows, p->N, p->eval_ptr,
-                                       eval_stride, p->ln_stats, parts, M, D));
+    F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos_ln(st, p->c1, D, p->convpos_w2, p->convpos_b2, p->x, D, p->h0, D, p->S, p->N, D,
+                                             p->convpos_groups, p->hn, D, p->mod + D, row_stride, p->mod_rows,
+                                             p->eval_ptr, eval_stride, p->ln_stats, parts));
     for (int l = 0; l < p->L; ++l) {
       const f5e_dit_block_weights& w = p->blocks[l];
       F5E_REQUIRE(!w.q_norm_w, "dit_forward: fused AdaLN and qk_norm are exclusive");

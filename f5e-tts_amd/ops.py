@@ -235,6 +235,20 @@ def convpos(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_bf
           "f5e_convpos")
 
 
+def convpos_ln(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_f32: Tensor, resid: Tensor, xs: Tensor,
+               scale: Tensor, stats: Tensor, eval_ptr: Optional[Tensor] = None, eval_stride: int = 0):
+    """Second position-embedding conv + head of the fused-AdaLN chain (``convpos`` mode 1 then ``adaln_pre``), one launch
+    when the grid fits the chip in one round."""
+    require_device()
+    D = x.shape[1]
+    check(lib().f5e_convpos_ln(_stream(), _p(x, BF, "x"), x.stride(0), _p(w_packed, BF, "w_packed"), _p(bias, F32, "bias"),
+                               _p(out_f32, F32, "out_f32"), out_f32.stride(0), _p(resid, F32, "resid"), resid.stride(0),
+                               S, N, D, w_packed.shape[0], _p(xs, BF, "xs"), xs.stride(0),
+                               C.c_void_p(scale.data_ptr()), scale.stride(0), scale.shape[0],
+                               _p(eval_ptr, I32, "eval_ptr"), eval_stride, _p(stats, F32, "stats"), stats.shape[1]),
+          "f5e_convpos_ln")
+
+
 def dwconv7(x: Tensor, w_t: Tensor, bias: Tensor, out: Tensor):
     require_device()
     B, T, Cc = x.shape

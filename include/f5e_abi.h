@@ -147,6 +147,15 @@ int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, con
                 void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
                 int groups);
 
+/* The second conv of ConvPositionEmbedding (mode 1 above) together with the head of the fused-AdaLN chain
+ * (f5e_adaln_pre on its output: xs = bf16(out (1 + scale)), statistics per row and 64-column tile).  One launch when the
+ * grid fits the chip in one round, D / groups == 64, parts == groups and mod_rows == 1; otherwise f5e_convpos followed
+ * by f5e_adaln_pre -- same results up to fp32 summation order.  Arguments as in those two functions. */
+int f5e_convpos_ln(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, float* out_f32,
+                   int ldo32, const float* resid, int ldr, int S, int N, int D, int groups, void* xs, int ld_xs,
+                   const float* scale, int mod_stride, int mod_rows, const int* eval_ptr, int eval_stride, float* stats,
+                   int parts);
+
 /* Depthwise Conv1d(C, C, 7, padding 3, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [7][C]. */
 int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
 

@@ -261,6 +261,35 @@ def test_convpos(ops, S, N, D, G):
     close(o32, F.mish(conv) + res, 1e-4, 2e-4, "mode 1")
 
 
+@pytest.mark.parametrize("S,N,D,G", [(2, 469, 1024, 16), (1, 70, 256, 4), (8, 300, 1024, 16), (2, 100, 768, 16)])
+def test_convpos_ln(ops, S, N, D, G):
+    """Second conv + head of the fused-AdaLN chain: one launch (first two cases) or conv + adaln_pre (ring kernel /
+    narrow groups) -- both must give out, xs = bf16(out (1 + scale)) and statistics that combine to the row mean / var."""
+    cpg, parts, M = D // G, D // 64, S * N
+    x = torch.randn(S, N, D, generator=g(41)).to(BF)
+    w = (torch.randn(D, cpg, 31, generator=g(42)) / math.sqrt(cpg * 31)).to(BF)
+    b = torch.randn(D, generator=g(43)) * 0.1
+    res = torch.randn(M, D, generator=g(44))
+    scale = torch.randn(3, 2 * D, generator=g(45)) * 0.2       # 3 evaluations; the scale row starts at column D
+    ev = torch.tensor([2], dtype=torch.int32)
+    conv = F.conv1d(x.float().permute(0, 2, 1), w.float(), b, padding=15, groups=G).permute(0, 2, 1).reshape(M, D)
+    wp = ops.pack_convpos_weight(w.float(), G)
+    o32 = torch.empty(M, D, device="cuda")
+    xs = torch.empty(M, D, device="cuda", dtype=BF)
+    stats = torch.zeros(M, parts, 2, device="cuda")
+    sc_dev = dev(scale)
+    ops.convpos_ln(dev(x.view(M, D)), dev(wp), dev(b), S, N, out_f32=o32, resid=dev(res), xs=xs,
+                   scale=sc_dev[:1, D:], stats=stats, eval_ptr=dev(ev), eval_stride=2 * D)
+    close(o32, F.mish(conv) + res, 1e-4, 2e-4, "out")
+    out = o32.cpu()
+    close(xs, (out * (1.0 + scale[2, D:])).to(BF).float(), 2 ** -7, 1e-3, "xs")
+    st = stats.cpu().double()
+    mean = st[:, :, 0].mean(1)                                 # equal tile sizes
+    m2 = st[:, :, 1].sum(1) + 64.0 * ((st[:, :, 0] - mean[:, None]) ** 2).sum(1)
+    close(mean.float(), out.mean(1), 1e-5, 1e-5, "mean from statistics")
+    close((m2 / D).float(), out.var(1, unbiased=False), 1e-5, 1e-4, "variance from statistics")
+
+
 def test_dwconv7_im2col(ops):
     B, T, C = 2, 50, 512
     x = torch.randn(B, T, C, generator=g(35))

@@ -1,6 +1,6 @@
 // Per-workgroup timeline of the bf16 GEMM kernel (diagnostic build, DBG == 3 stamps) inside a chain of dependent
 // launches replayed from a hipGraph.  Answers: where do the microseconds of a small-M launch go (launch gap, start
-// ramp, first tile, K loop, epilogue)?    usage: gemm_trace.bin <variant> <M> <N> <K> <epi: 0 bf16, 1 gelu, 2 gate_res>
+// ramp, first tile, K loop, epilogue)?    usage: gemm_trace.bin <variant> <M> <N> <K> <epi: 0 bf16, 1 gelu, 2 gate_res, 3 qkv+rope (2 sequences)>
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_trace.hip f5e-tts_amd/csrc/gemm_bf16_pp.hip -o tools/gemm_trace.bin
 #include <algorithm>
 #include <cstdarg>
@@ -61,6 +61,16 @@ int main(int argc, char** argv) {
   hipMalloc(&cd, (size_t)2 * N * 4);
   hipMemset(stats, 0, (size_t)M * 32 * 2 * 4);
   hipMemset(cd, 0, (size_t)2 * N * 4);
+  // qkv + rope: two sequences of M / 2 rows, heads = N / 192
+  const int rps = epi == 3 ? M / 2 : M, heads = N / 192, n_pad = (rps + 63) / 64 * 64;
+  bf16 *qb = nullptr, *kb = nullptr, *vtb = nullptr;
+  float* cs = nullptr;
+  if (epi == 3) {
+    const size_t hb = (size_t)2 * heads * n_pad * 64 * 2;
+    hipMalloc(&qb, hb); hipMalloc(&kb, hb); hipMalloc(&vtb, hb);
+    hipMalloc(&cs, (size_t)rps * 64 * 4);
+    hipMemset(cs, 0, (size_t)rps * 64 * 4);
+  }
   {  // small random-ish fill (values do not matter for timing, but keep them finite)
     std::vector<unsigned short> h((size_t)NW * N * K);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 25);  // ~[0.0078, 0.0156]
@@ -77,14 +87,15 @@ int main(int argc, char** argv) {
     GemmArgs a{};
     a.A = A; a.lda = K; a.W = W + (size_t)(l % NW) * N * K; a.ldw = K; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = N;
-    a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = M;
+    a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = rps;
+    if (epi == 3) { a.q = qb; a.k = kb; a.vt = vtb; a.n_pad = n_pad; a.heads = heads; a.rope_heads = heads; a.cos_sin = cs; }
     a.trace = trace + (size_t)l * max_grid * 48;
     if (variant == 10) {
       if (epi == 2) { a.xs_out = out; a.ld_xs = N; a.next_scale = gate; a.stats_out = stats; }
       else { a.ln_stats = stats; a.ln_parts = K / 64; a.ln_c = cd; a.ln_d = cd + N; a.cd_stride = 2 * N; a.cd_rows = 1;
              a.ln_eps = 1e-6f; a.bias = nullptr; }
     }
-    int rc = epi == 2 ? run_variant<EPI_GATE_RES>(variant, a, st, &bm, &bn)
+    int rc = epi == 3 ? run_variant<EPI_QKV_ROPE>(variant, a, st, &bm, &bn) : epi == 2 ? run_variant<EPI_GATE_RES>(variant, a, st, &bm, &bn)
                       : (epi == 1 ? run_variant<EPI_BF16_GELU>(variant, a, st, &bm, &bn) : run_variant<EPI_BF16>(variant, a, st, &bm, &bn));
     grid = a.tiles_m * a.tiles_n;
     return rc;
