@@ -25,6 +25,7 @@ struct Gemm32Args {
   bf16* out_bf16; int ldo_bf16;
   int M, N, K;
   int tiles_m;
+  int vec;  // epilogue may move 4 columns at a time (alignment checked on the host)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(Gemm32Args a) {
@@ -231,6 +232,40 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
     nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
 
+  if (a.vec) {
+    // N, leading dimensions and pointers are 16-byte friendly (host check): quads of 4 columns move as one piece and
+    // the addend rows are requested together, ahead of the arithmetic (one round trip instead of sixteen)
+    f32x4 add[TN][TM];
+    if (a.addend) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = min(m0 + wm0 + j * 16 + fr, a.M - 1);
+        const float* ap = a.addend + (size_t)(m % a.add_rows) * a.ld_add;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) add[i][j] = *(const f32x4*)(ap + min(n0 + wn0 + i * 16 + fq * 4, a.N - 4));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm0 + j * 16 + fr;
+      if (m >= a.M) continue;
+      const float rs = a.row_scale ? a.row_scale[m] : 1.0f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn0 + i * 16 + fq * 4;
+        if (n >= a.N) continue;
+        f32x4 v = acc[i][j];
+        if (a.bias) v += *(const f32x4*)(a.bias + n);
+        if (a.act != F5E_ACT_NONE) { v[0] = apply_act(v[0], a.act); v[1] = apply_act(v[1], a.act); v[2] = apply_act(v[2], a.act); v[3] = apply_act(v[3], a.act); }
+        if (a.ch_scale) v *= *(const f32x4*)(a.ch_scale + n);
+        if (a.addend) v += add[i][j];
+        v *= rs;
+        if (a.out) *(f32x4*)(a.out + (size_t)m * a.ldo + n) = v;
+        if (a.out_bf16) *(bf16x4*)(a.out_bf16 + (size_t)m * a.ldo_bf16 + n) = f2bf4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm0 + j * 16 + fr;
@@ -288,6 +323,8 @@ extern "C" int f5e_gemm_f32(hipStream_t st, const float* A, int lda, int a_rows,
   a.ch_scale = ch_scale; a.addend = addend; a.ld_add = ld_add; a.add_rows = add_rows > 0 ? add_rows : 1;
   a.row_scale = row_scale; a.out = out; a.ldo = ldo; a.out_bf16 = (bf16*)out_bf16; a.ldo_bf16 = ldo_bf16;
   a.M = M; a.N = N; a.K = K;
+  a.vec = N % 4 == 0 && N >= 4 && ldo % 4 == 0 && ldo_bf16 % 4 == 0 && ld_add % 4 == 0 &&
+          (((uintptr_t)bias | (uintptr_t)ch_scale | (uintptr_t)addend | (uintptr_t)out) & 15) == 0 && ((uintptr_t)out_bf16 & 7) == 0;
   if (a_act == F5E_ACT_NONE && (((uintptr_t)A | (uintptr_t)W) & 15) == 0) {  // K % 4 == 0 is checked above
     // few tiles: halve BM so more CUs take part (these GEMMs have M of a few hundred rows)
     if (((M + 63) / 64) * ((N + 63) / 64) < 128) return launch_dma<32, 64, 2, 2, 4>(a, st);
