@@ -148,9 +148,42 @@ __global__ __launch_bounds__(256) void grn_norm_kernel(const float* x, float* gx
   }
 }
 
+// GRN pass 1, C % 4 == 0: 16 row groups x 16 channel quads per workgroup, 8 independent 16-byte loads in flight per
+// thread (the scalar kernel above walks T / 4 rows with one 4-byte load at a time: 35 us for 469 x 1024)
+__global__ __launch_bounds__(256) void grn_norm4_kernel(const float* x, float* gx, int T, int C) {
+  __shared__ f32x4 red[16][16];
+  const int b = blockIdx.y;
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + q * 4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* xp = x + (size_t)b * T * C + c;
+    int t = rg;
+    for (; t + 7 * 16 < T; t += 8 * 16) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(xp + (size_t)(t + 16 * u) * C);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u] * v[u];
+    }
+    for (; t < T; t += 16) {
+      const f32x4 v = *(const f32x4*)(xp + (size_t)t * C);
+      s += v * v;
+    }
+  }
+  red[rg][q] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    f32x4 a = red[0][q];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) a += red[r][q];
+    *(f32x4*)(gx + (size_t)b * C + c) = f32x4{sqrtf(a[0]), sqrtf(a[1]), sqrtf(a[2]), sqrtf(a[3])};
+  }
+}
+
 // GRN pass 2: y = gamma * (x * gx / (mean_c gx + 1e-6)) + beta + x        (modules.py:231-234)
 __global__ __launch_bounds__(256) void grn_apply_kernel(const float* x, const float* gx, const float* gamma,
-                                                        const float* beta, float* y, int T, int C) {
+                                                        const float* beta, float* y, int T, int C, int vec) {
   __shared__ float s_mean;
   const int b = blockIdx.y;
   if (threadIdx.x < 64) {
@@ -162,6 +195,17 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* x, const fl
   __syncthreads();
   const float inv = 1.0f / (s_mean + 1e-6f);
   const size_t total = (size_t)T * C;
+  if (vec) {  // C % 4 == 0 and 16-byte aligned operands (host check): 4 channels per thread: no per-element modulo, 16-byte accesses
+    const size_t quads = total / 4;
+    const int cq = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) {
+      const int c = (int)(i % cq) * 4;
+      const f32x4 v = *(const f32x4*)(x + (size_t)b * total + i * 4);
+      const f32x4 g = *(const f32x4*)(gx + (size_t)b * C + c);
+      *(f32x4*)(y + (size_t)b * total + i * 4) = *(const f32x4*)(gamma + c) * (v * (g * inv)) + *(const f32x4*)(beta + c) + v;
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float v = x[(size_t)b * total + i];
@@ -242,11 +286,14 @@ int f5e_l2norm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int y_
 int f5e_grn(hipStream_t st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B,
             int T, int C) {
   F5E_REQUIRE(x && y && gx_ws && gamma && beta && B > 0 && T > 0 && C > 0, "grn: null/empty");
-  hipLaunchKernelGGL(grn_norm_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, gx_ws, T, C);
+  const bool vec = C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gx_ws | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(grn_norm4_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, gx_ws, T, C);
+  else hipLaunchKernelGGL(grn_norm_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, x, gx_ws, T, C);
   F5E_LAUNCH_CHECK("grn_norm");
   const size_t total = (size_t)T * C;
-  const int gx = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(grn_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, gx_ws, gamma, beta, y, T, C);
+  const size_t items = vec ? total / 4 : total;
+  const int gx = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+  hipLaunchKernelGGL(grn_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, gx_ws, gamma, beta, y, T, C, vec ? 1 : 0);
   F5E_LAUNCH_CHECK("grn_apply");
   return F5E_OK;
 }

@@ -199,8 +199,8 @@ def test_layernorm_variants(ops, D):
     close(out32, F.layer_norm(x, (D,), gam, bet, eps=1e-6), 1e-5, 1e-5, "ln affine f32")
 
 
-def test_grn(ops):
-    B, T, C = 2, 77, 192
+@pytest.mark.parametrize("B,T,C", [(2, 77, 192), (1, 469, 1024), (2, 300, 1024), (1, 33, 66), (3, 5, 64)])
+def test_grn(ops, B, T, C):
     x = torch.randn(B, T, C, generator=g(22))
     gam, bet = torch.randn(1, 1, C, generator=g(23)), torch.randn(1, 1, C, generator=g(24))
     out = torch.empty(B, T, C, device="cuda")
