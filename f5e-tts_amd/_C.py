@@ -29,6 +29,7 @@ SIGNATURES = {
     "f5e_l2norm": [_P, _P, _I, _P, _I, _I, _P, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
+    "f5e_debug_convpos_trace": [_P],
     "f5e_convpos_ln": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
@@ -53,7 +54,7 @@ SIGNATURES = {
     "f5e_graph_launch": [_P, _P],
     "f5e_graph_destroy": [_P],
 }
-_RESTYPE = {"f5e_last_error": C.c_char_p}
+_RESTYPE = {"f5e_last_error": C.c_char_p, "f5e_debug_convpos_trace": None}
 
 
 class BlockWeights(C.Structure):

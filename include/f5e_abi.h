@@ -260,6 +260,12 @@ int f5e_timer_destroy(void* timer);
 int f5e_timer_reset(void* timer);
 int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
 
+/* Diagnostics (tools/convpos_time.py): while buf != NULL, f5e_convpos / f5e_convpos_ln launch a build of their kernels
+ * that writes 8 timestamps per workgroup ([groups * tiles * S][8] uint64: s_memrealtime at entry, s_memtime at entry,
+ * first tile landed, two marks inside the tap loop, loop done, stores acknowledged, s_memrealtime at exit).  Process-wide,
+ * not for concurrent callers. */
+void f5e_debug_convpos_trace(void* buf);
+
 /* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
 int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
 

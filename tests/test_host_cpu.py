@@ -48,6 +48,9 @@ def test_abi_rejects_bad_shapes_without_launching():
     rc = lib.f5e_flash_attn(None, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1024, None, 1, 16, 100,
                             100, 0)
     assert rc == -1 and b"n_pad" in lib.f5e_last_error()
+    rc = lib.f5e_convpos_ln(None, C.c_void_p(8), 64, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 64, C.c_void_p(8), 64,
+                            1, 8, 64, 1, None, 64, C.c_void_p(8), 64, 1, None, 0, C.c_void_p(8), 1)
+    assert rc == -1 and b"convpos_ln" in lib.f5e_last_error()
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -57,8 +57,6 @@ with torch.cuda.stream(st):
         nwg = G * tiles * S
         buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
         hook = _C.lib().f5e_debug_convpos_trace
-        hook.argtypes = [ctypes.c_void_p]
-        hook.restype = None
         hook(ctypes.c_void_p(buf.data_ptr()))
         for i in range(6):  # last launch is what stays in the buffer
             ops.convpos(x, wps[(2 * i) % NW], b, S, N, out_bf16=c1)
