@@ -26,6 +26,9 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
     case 3: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3>(a, st);
     case 4: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 2, 2, 3>(a, st);
     case 5: *bm = 64; *bn = 64; return launch<64, 64, EPI, 2, 2, 2, 3>(a, st);
+    case 6: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 4, 3>(a, st);   // 8 waves (2 x 4), 4-stage ring
+    case 7: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 4, 3>(a, st);   // 8 waves, 3-stage ring
+    case 8: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 4, 2, 3>(a, st);   // 8 waves (4 x 2), 4-stage ring
     case 10:  // fused AdaLN: consumer for the bf16 / gelu epilogues, producer for gate + residual
       *bm = 64; *bn = 64;
       if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 3, 2, 2, 3, 2>(a, st);
