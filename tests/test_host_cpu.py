@@ -298,3 +298,17 @@ def test_full_size_layouts_match_reference_including_codebook():
                 cb_config=mc["transformer_codebook_config"])
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref[tag], tag
     assert len(ref["v1_base"]) == 364 and any(k.startswith("quantizer.") for k in ref["small_ppg_codebook"])
+
+
+def test_mish_closed_form_matches_the_definition():
+    """csrc/f5e_common.h mish_f: x tanh(softplus(x)) = x n / (n + 2), n = e (e + 2), e = exp(min(x, 20)); x > 20 -> x
+    (torch's softplus threshold, modules.py:167-190 uses nn.Mish).  The algebra is pinned here in fp32 against
+    F.mish in fp64; the GPU instruction accuracy is covered by the conv / activation parity tests."""
+    x = torch.linspace(-40, 40, 200001, dtype=torch.float32)
+    e = torch.exp(torch.clamp(x, max=20.0))
+    n = e * (e + 2)
+    y = torch.where(x > 20, x, x * (n / (n + 2)))
+    ref = torch.nn.functional.mish(x.double())
+    err = (y.double() - ref).abs()
+    assert bool((err <= 1e-7 + 1e-6 * ref.abs()).all()), float(err.max())
+
