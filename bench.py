@@ -105,20 +105,20 @@ def main():
         ppg_config = dict(use_ppg=True, ppg_dim=256, use_transformer=False)
         dit = DiT(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
                   text_mask_padding=False, pe_attn_head=1, ppg_config=ppg_config)
-        dit.load_state_dict(O.init_dit_state(cfg, 1234), strict=True)
+        dit.load_state_dict(SY.init_dit_state(cfg, 1234), strict=True)
         cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
     else:
         cfg = O.DiTConfig()
-        sd = O.init_dit_state(cfg, 1234)
+        sd = SY.init_dit_state(cfg, 1234)
         dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
         dit.load_state_dict(sd, strict=True)
         cfm = CFM(transformer=dit).cuda().eval()
-    vs = O.init_vocos_state()
+    vs = SY.init_vocos_state()
     voc = Vocos()
     voc.load_state_dict(vs, strict=False)
     voc = voc.cuda().eval()
-    wav = O.synthetic_ref_wave(N_REF, batch=BATCH).cuda()
-    text = O.synthetic_text_ids(N_TOTAL, batch=BATCH)   # token ids stay on the host, as the reference's callers hand them
+    wav = SY.synthetic_ref_wave(N_REF, batch=BATCH).cuda()
+    text = SY.synthetic_text_ids(N_TOTAL, batch=BATCH)   # token ids stay on the host, as the reference's callers hand them
 
     def one_pass():
         mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
@@ -146,7 +146,7 @@ def main():
         need = world * (args.steps + args.warmup)
         utts = [utts[i % len(utts)] for i in range(need)]
         mine = [utts[i] for i in lpt_partition([flop_fwd(t) for _, t in utts], world)[rank]]
-        inputs = [(O.synthetic_ref_wave(r).cuda(), O.synthetic_text_ids(t), r, t) for r, t in mine]
+        inputs = [(SY.synthetic_ref_wave(r).cuda(), SY.synthetic_text_ids(t), r, t) for r, t in mine]
         step_frames = [(t, t - r) for _, _, r, t in inputs[args.warmup:]]
         cursor = [0]
 

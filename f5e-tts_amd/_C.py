@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libf5e_hip.so")
+# F5E_HIP_LIB: diagnostics only (tools/convpos_time.py loads the -DF5E_TOOLS build); the product loads the in-tree library
+LIB_PATH = os.environ.get("F5E_HIP_LIB") or os.path.join(_HERE, "libf5e_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_MISH = range(6)
 
@@ -29,22 +30,24 @@ SIGNATURES = {
     "f5e_l2norm": [_P, _P, _I, _P, _I, _I, _P, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
-    "f5e_debug_convpos_trace": [_P],
     "f5e_convpos_ln": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
     "f5e_sinus_embed": [_P, _P, _P, _P, _I, _I, _F],
     "f5e_rope_table": [_P, _P, _P, _I, _I],
-    "f5e_text_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_text_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "f5e_ode_update": [_P, _P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _P, _LL],
     "f5e_ode_update_traj": [_P, _P, _LL, _I, _F, _F, _P, _P, _P, _LL, _I, _P, _P, _P, _LL],
     "f5e_advance_eval": [_P, _P],
     "f5e_stitch": [_P, _P, _P, _P, _P, _LL, _I],
     "f5e_cast_bf16": [_P, _P, _P, _LL],
+    "f5e_cast_f32": [_P, _P, _P, _LL],
+    "f5e_axpby": [_P, _P, _P, _P, _F, _F, _F, _LL],
     "f5e_vq_eval": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_dit_forward": [_P, _P],
+    "f5e_workspace_bytes": [_P, _P],
     "f5e_timer_create": [_I, C.POINTER(C.c_void_p)],
     "f5e_timer_destroy": [_P],
     "f5e_timer_reset": [_P],
@@ -54,7 +57,7 @@ SIGNATURES = {
     "f5e_graph_launch": [_P, _P],
     "f5e_graph_destroy": [_P],
 }
-_RESTYPE = {"f5e_last_error": C.c_char_p, "f5e_debug_convpos_trace": None}
+_RESTYPE = {"f5e_last_error": C.c_char_p}
 
 
 class BlockWeights(C.Structure):
@@ -81,6 +84,15 @@ class DitPlan(C.Structure):
         + [("timer", _P), ("timer_op", _I)]
         + [("fuse_ln", _I), ("ln_stats", _P), ("cd", _P), ("cd_stride", _I)]
     )
+
+WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp")
+
+
+class DitWorkspace(C.Structure):
+    """f5e_dit_workspace: byte size / arena offset of every caller-owned buffer of a plan (order = WS_NAMES)."""
+    _fields_ = [("n_pad", _I), ("bytes", C.c_ulonglong * len(WS_NAMES)), ("offset", C.c_ulonglong * len(WS_NAMES)),
+                ("total", C.c_ulonglong)]
+
 
 OP_NONE, OP_INPROJ, OP_CONVPOS, OP_LN, OP_QKV, OP_ATTN, OP_OUT, OP_FF1, OP_FF2, OP_FINAL = range(10)
 

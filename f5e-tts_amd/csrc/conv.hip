@@ -432,12 +432,23 @@ inline int grid_for(size_t total) {
 
 }  // namespace
 
+// Diagnostics hook of the TOOLS build only (make tools-lib -> libf5e_hip_tools.so, -DF5E_TOOLS; tools/convpos_time.py):
+// the shipped library has no process-wide mutable state and does not export it.
+#ifdef F5E_TOOLS
 static unsigned long long* g_convpos_trace = nullptr;
+#define F5E_CONVPOS_TRACE g_convpos_trace
+#else
+#define F5E_CONVPOS_TRACE ((unsigned long long*)nullptr)
+#endif
 
 extern "C" {
 
-// diagnostics hook (tools/convpos_time.py): 8 timestamps per workgroup of the next f5e_convpos launches
+#ifdef F5E_TOOLS
+// 8 timestamps per workgroup of the next f5e_convpos launches: [groups * tiles * S][8] uint64 (s_memrealtime at entry,
+// s_memtime at entry, first tile landed, two marks inside the tap loop, loop done, stores acknowledged, s_memrealtime at
+// exit) while buf != NULL.  Process-wide, not for concurrent callers.
 void f5e_debug_convpos_trace(void* buf) { g_convpos_trace = (unsigned long long*)buf; }
+#endif
 
 // fuse: optional head-of-chain outputs (xs, scale, stats ...) already filled into *fuse; applied only when the
 // split-tap kernel is the one that runs -- *fused says whether it did
@@ -466,7 +477,7 @@ static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_
   // workgroup per CU, e.g. batch 1 with CFG: 256 workgroups) are bound by weight delivery and LDS reads -> split-tap
   // kernel (140 KB LDS); larger grids take the output-split ring (44 KB LDS, 3 workgroups per CU overlap each other).
   static const int forced = getenv("F5E_CONVPOS") ? atoi(getenv("F5E_CONVPOS")) : 0;  // diagnostics: 1 split, 2 ring
-  static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int n_cu = f5e_cu_count();
   const bool split = forced ? forced == 1 : (size_t)groups * a.tiles_t * S <= (size_t)n_cu;
   if (fused) *fused = false;
   if (fuse && split && cpg == 64) {
@@ -475,17 +486,20 @@ static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_
     *fused = true;
   }
   const int lds_split = xs + 4 * 4 * 8192, lds_ring = xs + 4 * 8192;
-  a.trace = g_convpos_trace;
-  if (split) {
-    if (a.trace) {
-      (void)hipFuncSetAttribute((const void*)convpos_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_split);
-      hipLaunchKernelGGL(convpos_split_kernel<true>, grid, dim3(256), lds_split, st, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)convpos_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_split);
-      hipLaunchKernelGGL(convpos_split_kernel<false>, grid, dim3(256), lds_split, st, a);
-    }
+  a.trace = F5E_CONVPOS_TRACE;
+  static F5eDeviceOnce once_split;
+  if (split) F5E_OPT_IN_LDS(once_split, convpos_split_kernel<false>, lds_split);
+#ifdef F5E_TOOLS
+  static F5eDeviceOnce once_split_trace;
+  if (split && a.trace) {
+    F5E_OPT_IN_LDS(once_split_trace, convpos_split_kernel<true>, lds_split);
+    hipLaunchKernelGGL(convpos_split_kernel<true>, grid, dim3(256), lds_split, st, a);
   } else if (a.trace) {
     hipLaunchKernelGGL((convpos_kernel<4, true>), grid, dim3(256), lds_ring, st, a);
+  } else
+#endif
+  if (split) {
+    hipLaunchKernelGGL(convpos_split_kernel<false>, grid, dim3(256), lds_split, st, a);
   } else {
     hipLaunchKernelGGL((convpos_kernel<4, false>), grid, dim3(256), lds_ring, st, a);
   }

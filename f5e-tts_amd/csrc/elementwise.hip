@@ -36,14 +36,17 @@ __global__ void rope_table_kernel(const float* inv_freq, float* out, int N, int 
 
 // TextEmbedding front half (backbones/dit.py:68-80): out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]
 __global__ void text_gather_kernel(const int* ids, const float* table, const float* pos, const float* keep, float* out,
-                                   int B, int N, int TD, int max_pos) {
+                                   int B, int N, int TD, int max_pos, int table_rows) {
   const int td4 = TD / 4;
   const size_t total = (size_t)B * N * td4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % td4) * 4;
     const size_t bn = i / td4;
     const int n = (int)(bn % N);
-    f32x4 v = *(const f32x4*)(table + (size_t)ids[bn] * TD + c);
+    // ids are validated on the host where they start there (CFM._prepare raises IndexError like nn.Embedding); the clamp
+    // keeps a bad id handed over as a device tensor from reading outside the table
+    const int id = min(max(ids[bn], 0), table_rows - 1);
+    f32x4 v = *(const f32x4*)(table + (size_t)id * TD + c);
     if (pos) v += *(const f32x4*)(pos + (size_t)min(n, max_pos - 1) * TD + c);
     if (keep) v *= keep[bn];
     *(f32x4*)(out + bn * TD + c) = v;
@@ -103,6 +106,16 @@ __global__ void stitch_kernel(const float* cond, const float* y, const unsigned 
 
 __global__ void cast_bf16_kernel(const float* x, bf16* y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (bf16)x[i];
+}
+
+__global__ void cast_f32_kernel(const bf16* x, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+// out = a x + b y (+ c): the duplicate_test start state (1 - t) y0 + t cond (cfm.py:463) and "1 + scale" rows
+__global__ void axpby_kernel(const float* x, const float* y, float* out, float a, float b, float c, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.0f) + c;
 }
 
 // GumbelVectorQuantizer.forward in eval mode (reference model/modules.py:881-950): per (row, group) argmax of the
@@ -200,10 +213,10 @@ int f5e_rope_table(hipStream_t st, const float* inv_freq, float* out, int N, int
 }
 
 int f5e_text_gather(hipStream_t st, const int* ids, const float* table, const float* pos, const float* keep,
-                    float* out, int B, int N, int TD, int max_pos) {
-  F5E_REQUIRE(ids && table && out && B > 0 && N > 0 && TD > 0 && TD % 4 == 0, "text_gather: bad arguments");
+                    float* out, int B, int N, int TD, int max_pos, int table_rows) {
+  F5E_REQUIRE(ids && table && out && B > 0 && N > 0 && TD > 0 && TD % 4 == 0 && table_rows > 0, "text_gather: bad arguments");
   hipLaunchKernelGGL(text_gather_kernel, dim3(grid_for((size_t)B * N * TD / 4)), dim3(256), 0, st, ids, table, pos,
-                     keep, out, B, N, TD, max_pos);
+                     keep, out, B, N, TD, max_pos, table_rows);
   F5E_LAUNCH_CHECK("text_gather");
   return F5E_OK;
 }
@@ -264,6 +277,20 @@ int f5e_cast_bf16(hipStream_t st, const float* x, void* y, long long n) {
   F5E_REQUIRE(x && y && n > 0, "cast_bf16: bad arguments");
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, x, (bf16*)y, (size_t)n);
   F5E_LAUNCH_CHECK("cast_bf16");
+  return F5E_OK;
+}
+
+int f5e_cast_f32(hipStream_t st, const void* x, float* y, long long n) {
+  F5E_REQUIRE(x && y && n > 0, "cast_f32: bad arguments");
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, (const bf16*)x, y, (size_t)n);
+  F5E_LAUNCH_CHECK("cast_f32");
+  return F5E_OK;
+}
+
+int f5e_axpby(hipStream_t st, const float* x, const float* y, float* out, float a, float b, float c, long long n) {
+  F5E_REQUIRE(x && out && n > 0, "axpby: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, x, y, out, a, b, c, (size_t)n);
+  F5E_LAUNCH_CHECK("axpby");
   return F5E_OK;
 }
 

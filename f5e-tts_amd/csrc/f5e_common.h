@@ -26,6 +26,47 @@ void f5e_set_error(const char* fmt, ...);
     }                                                  \
   } while (0)
 
+// Per-device host-side caches (a process may drive several GPUs, one per thread): the > 64 KiB dynamic-LDS opt-in is a
+// per-device function attribute, and the CU count differs per device.  Lock-free and idempotent: two threads racing on
+// the same device both set the attribute, which is harmless.
+#include <atomic>
+inline int f5e_device_index() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev < 0 ? 0 : (dev > 63 ? 63 : dev);
+}
+struct F5eDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+};
+// returns hipSuccess, or the error of hipFuncSetAttribute (the launch would fail with "invalid value" otherwise)
+inline hipError_t f5e_opt_in_lds(F5eDeviceOnce& once, const void* kernel, int lds_bytes) {
+  const unsigned long long bit = 1ull << f5e_device_index();
+  if (once.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e == hipSuccess) once.done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+#define F5E_OPT_IN_LDS(once, kernel, lds)                                                    \
+  do {                                                                                       \
+    hipError_t e_ = f5e_opt_in_lds(once, (const void*)(kernel), lds);                        \
+    if (e_ != hipSuccess) {                                                                  \
+      f5e_set_error("hipFuncSetAttribute(%d B of LDS): %s", (int)(lds), hipGetErrorString(e_)); \
+      return F5E_ERR_HIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+inline int f5e_cu_count() {
+  static std::atomic<int> cache[64];
+  const int dev = f5e_device_index();
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    n = v;
+  }
+  return n;
+}
+
 // No synchronisation here: only picks up launch-configuration errors, so every op stays graph-capturable.
 #define F5E_LAUNCH_CHECK(name)                                                   \
   do {                                                                           \

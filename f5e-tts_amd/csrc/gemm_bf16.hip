@@ -464,12 +464,8 @@ int launch(GemmArgs& a, hipStream_t st) {
   a.rps_magic = div_magic_of(a.rows_per_seq);
   const int grid = a.tiles_m * a.tiles_n;
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2 + (FUSE ? 1024 : 0);
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
-  if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), lds);
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;

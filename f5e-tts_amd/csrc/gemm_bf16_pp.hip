@@ -444,19 +444,10 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_n = (a.N + 255) / 256;
   a.m_major = a.M > a.N;
   constexpr int lds = 8 * HALF_BYTES;
-  static bool attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    n_cu = v > 0 ? v / 8 * 8 : 256;
-    if (n_cu == 0) n_cu = 8;
-  }
+  static F5eDeviceOnce lds_once;  // 128 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
+  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG>), lds);
+  int n_cu = f5e_cu_count() / 8 * 8;
+  if (n_cu == 0) n_cu = 8;
   const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
   a.pp_stagger = (se && se[0] == '0') ? 0 : ((se && se[0] == '2') ? 2 : 1);
   const int n_tiles = a.tiles_m * a.tiles_n;

@@ -296,12 +296,8 @@ int launch_dma(Gemm32Args& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   const int grid = a.tiles_m * ((a.N + BN - 1) / BN);
   constexpr int lds = NSTAGE * (BM + BN) * 256;
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, host-only call)
-  if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), lds);
   hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), dim3(grid), dim3(256), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_f32_dma");
   return F5E_OK;

@@ -77,6 +77,32 @@ int f5e_graph_destroy(void* graph_exec) {
   return F5E_OK;
 }
 
+int f5e_workspace_bytes(const f5e_dit_plan* p, f5e_dit_workspace* out) {
+  F5E_REQUIRE(p && out, "workspace_bytes: null argument");
+  F5E_REQUIRE(p->S > 0 && p->N > 0 && p->D > 0 && p->H > 0 && p->FF > 0 && p->mel > 0, "workspace_bytes: bad shape");
+  const unsigned long long M = (unsigned long long)p->S * p->N, D = p->D, inner = (unsigned long long)p->H * 64;
+  const unsigned long long n_pad = ((unsigned long long)p->N + 63) / 64 * 64;
+  const unsigned long long qk = (unsigned long long)p->S * p->H * n_pad * 64 * 2;
+  memset(out, 0, sizeof(*out));
+  out->n_pad = (int)n_pad;
+  unsigned long long* b = out->bytes;
+  b[F5E_WS_H0] = M * D * 4;       b[F5E_WS_H0_BF16] = M * D * 2;  b[F5E_WS_C1] = M * D * 2;
+  b[F5E_WS_X] = M * D * 4;        b[F5E_WS_HN] = M * D * 2;
+  b[F5E_WS_Q] = qk;               b[F5E_WS_K] = qk;               b[F5E_WS_VT] = qk;
+  b[F5E_WS_AO] = M * inner * 2;   b[F5E_WS_FF] = M * (unsigned long long)p->FF * 2;
+  b[F5E_WS_PRED] = M * (unsigned long long)p->mel * 4;
+  b[F5E_WS_LN_STATS] = p->fuse_ln ? M * (D / 64) * 2 * 4 : 0;
+  b[F5E_WS_SKIP_RES] = p->w_skip ? M * D * 4 : 0;
+  b[F5E_WS_SKIP_TMP] = p->w_skip ? M * D * 4 : 0;
+  unsigned long long off = 0;
+  for (int i = 0; i < F5E_WS_COUNT; ++i) {
+    out->offset[i] = off;
+    off += (b[i] + 255) / 256 * 256;
+  }
+  out->total = off;
+  return F5E_OK;
+}
+
 struct F5eTimer {
   int capacity, count;
   hipEvent_t* start;

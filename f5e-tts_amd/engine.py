@@ -139,7 +139,7 @@ class DiTEngine:
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
         # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
         self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
-        self._graphs: Dict[tuple, "_LoopGraph"] = {}
+        self._loops = threading.local()   # per-thread LRU of persistent loop states (see _LoopState)
         self._tables: Dict[tuple, Tensor] = {}
         self._lock = threading.Lock()
         if not blocks:
@@ -196,8 +196,8 @@ class DiTEngine:
         one_plus = torch.empty(E * rows, D, device=dv)
 
         def pair(scale, shift, w_bf, bias, off, n):
-            w = w_bf.float()
-            torch.add(scale, 1.0, out=one_plus)
+            w = ops.cast_f32(w_bf, torch.empty(w_bf.shape, device=dv))     # the bf16 values the MFMA kernels read
+            ops.axpby(scale.contiguous(), None, one_plus, 1.0, 0.0, 1.0)
             ops.gemm_f32(one_plus, w, None, out=cd[:, off:off + n])
             ops.gemm_f32(shift, w, bias, out=cd[:, off + n:off + 2 * n])
 
@@ -210,21 +210,30 @@ class DiTEngine:
         pair(mf[:, :D], mf[:, D:2 * D], self.proj_w, self.proj_b, L * ls, mel)
         return cd.view(E, rows, stride)
 
-    def time_tables_cached(self, t_host: Tensor):
-        """(mod, cd) tables: they depend on the time grid only, so calls that share (steps, sway, solver) share them.
-        The cache is keyed by the exact grid values and is read-only once built (safe to share between threads).
-        cd is None when the architecture rules the fused AdaLN out."""
-        key = tuple(t_host.tolist())
+    def time_tables_cached(self, t_host: Tensor, coef_host: Optional[Tensor] = None):
+        """(mod, cd, coef) tables: they depend on the time grid only, so calls that share (steps, sway, solver) share
+        them.  The cache is keyed by the exact grid values and is read-only once built.  Every entry carries the event
+        recorded behind its build kernels: a caller on ANOTHER stream (a second thread sampling inside
+        `with torch.cuda.stream(s)`) orders its stream behind that event before it reads the tables -- without it the
+        hit would race the build still queued on the first caller's stream.  cd is None when the architecture rules the
+        fused AdaLN out; coef is the device copy of `coef_host` (step coefficients of the solver)."""
+        key = tuple(t_host.tolist()) + (("c",) + tuple(coef_host.tolist()) if coef_host is not None else ())
         with self._lock:
             hit = self._tables.get(key)
         if hit is None:
             mod = self.time_tables(h2d(t_host, self.device))
-            hit = (mod, self.cd_tables(mod) if self.can_fuse_ln else None)
+            cd = self.cd_tables(mod) if self.can_fuse_ln else None
+            coef = h2d(coef_host, self.device).contiguous() if coef_host is not None else None
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            hit = (mod, cd, coef, ev)
             with self._lock:
                 if len(self._tables) >= 8:
                     self._tables.pop(next(iter(self._tables)))
                 self._tables[key] = hit
-        return hit
+        else:
+            torch.cuda.current_stream(self.device).wait_event(hit[3])
+        return hit[:3]
 
     def time_embed(self, flat_t: Tensor) -> Tensor:
         """TimestepEmbedding (modules.py:721-731): f32 [n] -> f32 [n, dim]."""
@@ -333,24 +342,44 @@ class DiTEngine:
 
     # ------------------------------------------------------------------ plan / workspace
 
+    def plan_shape(self, S: int, B: int, N: int, mod_rows: int, fuse: bool) -> "_C.DitPlan":
+        """The shape half of a plan (what f5e_workspace_bytes reads)."""
+        cfg = self.cfg
+        p = _C.DitPlan()
+        p.S, p.B, p.N, p.n_pad, p.D, p.H = S, B, N, (N + 63) // 64 * 64, cfg.dim, cfg.heads
+        p.rope_heads, p.FF, p.L, p.mel, p.mod_rows = self.rope_heads, self.FF, self.L, cfg.mel_dim, mod_rows
+        p.fuse_ln = 1 if fuse else 0
+        if self.skip_w is not None:
+            p.w_skip = self.skip_w.data_ptr()
+        return p
+
+    def workspace(self, p: "_C.DitPlan") -> Tuple["_C.DitWorkspace", Tensor]:
+        """ONE arena sized and laid out by the library (f5e_workspace_bytes); q / k / vt pads zero-filled once."""
+        import ctypes as C
+        w = _C.DitWorkspace()
+        _C.check(_C.lib().f5e_workspace_bytes(C.byref(p), C.byref(w)), "f5e_workspace_bytes")
+        arena = torch.empty(int(w.total), dtype=torch.uint8, device=self.device)
+        q0 = int(w.offset[_C.WS_NAMES.index("q")])
+        q1 = int(w.offset[_C.WS_NAMES.index("vt")] + w.bytes[_C.WS_NAMES.index("vt")])
+        arena[q0:q1].zero_()
+        return w, arena
+
     def make_plan(self, S: int, B: int, N: int, y: Tensor, in_const: Tensor, mod: Tensor, eval_ptr: Optional[Tensor],
                   rope_cs: Tensor, seq_len: Optional[Tensor], pred: Optional[Tensor] = None,
                   cd: Optional[Tensor] = None) -> "_Plan":
-        cfg, dv = self.cfg, self.device
-        D, H, mel = cfg.dim, cfg.heads, cfg.mel_dim
-        n_pad = (N + 63) // 64 * 64
+        cfg = self.cfg
         M = S * N
-        ws = dict(
-            h0=torch.empty(M, D, device=dv), h0_bf16=torch.empty(M, D, device=dv, dtype=BF),
-            c1=torch.empty(M, D, device=dv, dtype=BF), x=torch.empty(M, D, device=dv),
-            hn=torch.empty(M, D, device=dv, dtype=BF),
-            q=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF), k=torch.zeros(S, H, n_pad, 64, device=dv, dtype=BF),
-            vt=torch.zeros(S, H, 64, n_pad, device=dv, dtype=BF),
-            ao=torch.empty(M, self.inner, device=dv, dtype=BF), ff=torch.empty(M, self.FF, device=dv, dtype=BF),
-            pred=pred if pred is not None else torch.empty(M, mel, device=dv))
-        p = _C.DitPlan()
-        p.S, p.B, p.N, p.n_pad, p.D, p.H = S, B, N, n_pad, D, H
-        p.rope_heads, p.FF, p.L, p.mel, p.mod_rows = self.rope_heads, self.FF, self.L, mel, mod.shape[1]
+        fuse = bool(cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS and cd.shape[1] == 1)
+        p = self.plan_shape(S, B, N, mod.shape[1], fuse)
+        w, arena = self.workspace(p)
+        assert int(w.n_pad) == p.n_pad
+        base = arena.data_ptr()
+        for i, name in enumerate(_C.WS_NAMES):
+            if w.bytes[i]:
+                setattr(p, name, base + int(w.offset[i]))
+        o, nb = int(w.offset[_C.WS_NAMES.index("pred")]), int(w.bytes[_C.WS_NAMES.index("pred")])
+        pred_t = pred if pred is not None else arena[o:o + nb].view(F32).view(M, cfg.mel_dim)
+        p.pred = pred_t.data_ptr()
         p.y = y.data_ptr()
         p.w_x, p.ldw_x = self.in_w.data_ptr(), self.in_w.stride(0)
         p.in_const = in_const.data_ptr()
@@ -363,15 +392,9 @@ class DiTEngine:
         p.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
         p.blocks = self.block_arr
         p.w_proj, p.b_proj = self.proj_w.data_ptr(), self.proj_b.data_ptr()
-        if self.skip_w is not None:
-            ws["skip_res"], ws["skip_tmp"] = torch.empty(M, D, device=dv), torch.empty(M, D, device=dv)
-            p.w_skip = self.skip_w.data_ptr()
-        for k, t in ws.items():
-            setattr(p, k, t.data_ptr())
-        if cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS and cd.shape[1] == 1:
-            ws["ln_stats"] = torch.empty(M, D // 64, 2, device=dv)
-            p.fuse_ln, p.ln_stats, p.cd, p.cd_stride = 1, ws["ln_stats"].data_ptr(), cd.data_ptr(), cd.shape[2]
-        return _Plan(p, ws, (y, in_const, mod, eval_ptr, rope_cs, seq_len, cd))
+        if fuse:
+            p.cd, p.cd_stride = cd.data_ptr(), cd.shape[2]
+        return _Plan(p, dict(arena=arena, pred=pred_t), (y, in_const, mod, eval_ptr, rope_cs, seq_len, cd), w)
 
     def forward(self, plan: "_Plan") -> Tensor:
         ops.dit_forward(plan.c)
@@ -379,17 +402,34 @@ class DiTEngine:
 
 
 class _Plan:
-    def __init__(self, c_plan, ws, keep):
-        self.c, self.ws, self.keep = c_plan, ws, keep
+    def __init__(self, c_plan, ws, keep, layout=None):
+        self.c, self.ws, self.keep, self.layout = c_plan, ws, keep, layout
 
 
-class _LoopGraph:
-    """A captured ODE step bound to fixed buffers; guarded by a lock because replay mutates those buffers."""
+class _LoopState:
+    """Everything one (thread, shape) pair needs to integrate again WITHOUT allocating or capturing: the workspace
+    arenas, the once-per-call buffers the captured kernels read (in_const, rope table, lengths, counters, ODE state,
+    trajectory) and the instantiated hipGraphs.  The first call with a key captures ONE step and replays it `steps`
+    times (cheap for shapes that never come back, e.g. an eval stream of distinct lengths); from the second call on the
+    WHOLE loop is one graph launch -- no capture, and none of the 8.6 us of idle the GPU spends between two graph
+    launches.  A state belongs to the thread (= side stream) that made it: all writes to its buffers are ordered on
+    that stream, which is what makes the reuse safe without host synchronisation."""
 
     def __init__(self):
-        self.lock = threading.Lock()
-        self.graph: Optional[ops.Graph] = None
+        self.uses = 0
+        self.step_graph: Optional[ops.Graph] = None
+        self.loop_graph: Optional[ops.Graph] = None
         self.buf: dict = {}
+        self.plans_a = self.plans_b = None
+
+    def retire(self):
+        for g in (self.step_graph, self.loop_graph):
+            if g is not None:
+                g.retire()
+        self.step_graph = self.loop_graph = None
+
+
+LOOP_CACHE_ENTRIES = 8   # per thread; a C4-style stream of distinct lengths just cycles through them
 
 
 @dataclass
@@ -465,10 +505,27 @@ def ode_setup(engine: DiTEngine, inp: SamplerInputs) -> dict:
         coef = torch.stack((half, dt), 1).reshape(-1)
     else:
         raise _C.F5EError(f"unsupported ODE method {inp.method!r} (euler, midpoint)")
-    mod, cd = engine.time_tables_cached(t_eval)                   # [E, 1, row_stride], [E, 1, cd_stride] or None
+    mod, cd, coef_d = engine.time_tables_cached(t_eval, coef)     # [E, 1, row_stride], [E, 1, cd_stride] or None, [E]
     seq_len = h2d(inp.seq_len, dv, I32) if inp.seq_len is not None else None
     return dict(steps=steps, eps_per_step=eps_per_step, mod=mod, cd=cd if engine.fuse_ln else None,
-                coef_d=h2d(coef, dv).contiguous(), seq_len=seq_len)
+                coef_d=coef_d, seq_len=seq_len)
+
+
+def _loop_state(engine: DiTEngine, key: tuple, persistent: bool) -> Tuple[_LoopState, bool]:
+    """The calling thread's state for `key` (LRU), or a throw-away one for eager / instrumented runs."""
+    if not persistent:
+        return _LoopState(), True
+    cache = getattr(engine._loops, "cache", None)
+    if cache is None:
+        cache = engine._loops.cache = {}
+    st = cache.pop(key, None)
+    fresh = st is None
+    if fresh:
+        st = _LoopState()
+        while len(cache) >= LOOP_CACHE_ENTRIES:
+            cache.pop(next(iter(cache))).retire()      # parked behind an event, destroyed once its launches ran
+    cache[key] = st                                     # most recently used last
+    return st, fresh
 
 
 def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
@@ -483,13 +540,42 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     B, N, mel = inp.y0.shape
     nb = len(inp.branches)
     S = nb * B
-    caller_setup = setup is not None
     if setup is None:
         setup = ode_setup(engine, inp)
     steps, eps_per_step, mod, cd = setup["steps"], setup["eps_per_step"], setup["mod"], setup["cd"]
+    coef_d = setup["coef_d"]
+    n_chains = chains or 1
+    if nb % n_chains:
+        raise _C.F5EError(f"chains={n_chains} must divide the number of CFG branches {nb}")
+    per = nb // n_chains  # branches per chain
+    engine.last_n_chains = n_chains
+    n = B * N * mel
+    masked = setup["seq_len"] is not None
 
-    # once-per-call tensors
-    in_const = torch.empty(S * N, cfg.dim, device=dv)
+    # Chains (opt-in): the CFG branches are independent until the combine, so they can run as PARALLEL chains of the
+    # captured graph.  Measured on MI355X at C2 (tools/chain_ab.py): 57-70 ms/pass with high run-to-run variance vs
+    # a stable 60.5 ms for the single batched forward, so the default keeps ONE forward over all branches (weights
+    # stream once per step); results are bit-identical either way.
+    persistent = use_graph and steps > 1 and timer is None
+    key = (S, B, N, nb, inp.mode, float(inp.w0), float(inp.w1), inp.method, steps, want_trajectory, n_chains, masked,
+           mod.data_ptr(), cd.data_ptr() if cd is not None else 0, coef_d.data_ptr())
+    st, fresh = _loop_state(engine, key, persistent)
+    bf = st.buf
+    if fresh:
+        bf["keep"] = (mod, cd, coef_d)      # the captured kernels read these: keep them alive past a table-cache eviction
+        bf["in_const"] = torch.empty(S * N, cfg.dim, device=dv)
+        bf["rope_cs"] = engine.rope_table(N)
+        bf["seq_len"] = torch.empty(S, dtype=I32, device=dv) if masked else None
+        bf["ctr"] = torch.zeros(2, dtype=I32, device=dv)     # [0] evaluation counter, [1] ode_update's arrival counter
+        bf["traj"] = torch.empty((steps + 1) if want_trajectory else 2, B, N, mel, device=dv)
+        bf["y"] = torch.empty(B, N, mel, device=dv)
+        bf["y_mid"] = torch.empty(B, N, mel, device=dv) if eps_per_step == 2 else None
+        bf["pred_all"] = torch.empty(S * N, mel, device=dv)
+    in_const, rope_cs, seq_len, traj, y, y_mid, pred_all = (bf[k] for k in ("in_const", "rope_cs", "seq_len", "traj", "y",
+                                                                          "y_mid", "pred_all"))
+    eval_ptr, done = bf["ctr"][0:1], bf["ctr"][1:2]
+
+    # once-per-call tensors, written into the persistent buffers
     cache: Dict[tuple, Tensor] = {}
     for bi, (da, dt_, dp) in enumerate(inp.branches):
         tk = ("t", dt_)
@@ -502,39 +588,25 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
                 cache[pk] = engine.ppg_embed(inp.ppg, B, N, dp)
             pe = cache[pk]
         engine.input_const(inp.step_cond, cache[tk], pe, da, in_const[bi * B * N:(bi + 1) * B * N])
-    rope_cs = engine.rope_table(N)
-    seq_len = setup["seq_len"].repeat(nb).contiguous() if setup["seq_len"] is not None else None
-    coef_d = setup["coef_d"]
-    eval_ptr = torch.zeros(1, dtype=I32, device=dv)
-    done = torch.zeros(1, dtype=I32, device=dv)
-    n = B * N * mel
-    traj = torch.empty((steps + 1) if want_trajectory else 2, B, N, mel, device=dv)
+    if masked:
+        seq_len.copy_(setup["seq_len"].repeat(nb))
+    bf["ctr"].zero_()
+    y.copy_(inp.y0)
     traj[0].copy_(inp.y0)
-    y = inp.y0.detach().clone().contiguous()
-    y_mid = torch.empty_like(y) if eps_per_step == 2 else None
 
-    # Chains (opt-in): the CFG branches are independent until the combine, so they can run as PARALLEL chains of the
-    # captured graph.  Measured on MI355X at C2 (tools/chain_ab.py): 57-70 ms/pass with high run-to-run variance vs
-    # a stable 60.5 ms for the single batched forward, so the default keeps ONE forward over all branches (weights
-    # stream once per step); results are bit-identical either way.
-    n_chains = chains or 1
-    if nb % n_chains:
-        raise _C.F5EError(f"chains={n_chains} must divide the number of CFG branches {nb}")
-    per = nb // n_chains  # branches per chain
-    engine.last_n_chains = n_chains
-    pred_all = torch.empty(S * N, mel, device=dv)
+    if fresh:
+        def plans_for(y_in):
+            out = []
+            for c in range(n_chains):
+                lo, hi = c * per * B * N, (c + 1) * per * B * N
+                sl = seq_len[c * per * B:(c + 1) * per * B] if seq_len is not None else None
+                out.append(engine.make_plan(per * B, B, N, y_in, in_const[lo:hi], mod, eval_ptr, rope_cs, sl,
+                                            pred=pred_all[lo:hi], cd=cd))
+            return out
 
-    def plans_for(y_in):
-        out = []
-        for c in range(n_chains):
-            lo, hi = c * per * B * N, (c + 1) * per * B * N
-            sl = seq_len[c * per * B:(c + 1) * per * B].contiguous() if seq_len is not None else None
-            out.append(engine.make_plan(per * B, B, N, y_in, in_const[lo:hi], mod, eval_ptr, rope_cs, sl,
-                                        pred=pred_all[lo:hi], cd=cd))
-        return out
-
-    plans_a = plans_for(y)
-    plans_b = plans_for(y_mid) if y_mid is not None else None
+        st.plans_a = plans_for(y)
+        st.plans_b = plans_for(y_mid) if y_mid is not None else None
+    plans_a, plans_b = st.plans_a, st.plans_b
     if timer is not None:
         if use_graph:
             raise _C.F5EError("KernelTimer brackets eager launches only (use_graph=False)")
@@ -552,12 +624,12 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
-        for pl, st in zip(plans[1:], aux_streams):
-            st.wait_event(fork)
-            with torch.cuda.stream(st):
+        for pl, st_ in zip(plans[1:], aux_streams):
+            st_.wait_event(fork)
+            with torch.cuda.stream(st_):
                 engine.forward(pl)
                 ev = torch.cuda.Event()
-                ev.record(st)
+                ev.record(st_)
             joins.append(ev)
         engine.forward(plans[0])
         for ev in joins:
@@ -574,26 +646,36 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             forward_all(plans_b)
             ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done, **kw)
 
-    if use_graph and steps > 1:
-        ops.Graph.reap()
+    def capture(reps: int) -> ops.Graph:
         gr = ops.Graph()
         gr.begin()
         try:
-            one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
+            for _ in range(reps):
+                one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
         finally:
             gr.end()
-        for i in range(steps):
-            gr.launch()
-        # the launches are still queued: the executable graph may only be destroyed once they have run.  The event that
-        # guards it must NOT live on this (capture) stream -- another thread polling it while this stream is capturing
-        # again invalidates that capture -- so a caller that owns the stream choreography retires it on its own stream
-        if caller_setup:
-            setup["graph"] = gr
+        return gr
+
+    if persistent:
+        ops.Graph.reap()
+        st.uses += 1
+        if st.loop_graph is None and st.uses >= 2 and LOOP_GRAPH:
+            st.loop_graph = capture(steps)         # this shape came back: from now on one launch per call
+        if st.loop_graph is not None:
+            st.loop_graph.launch()
         else:
-            gr.retire()
+            if st.step_graph is None:
+                st.step_graph = capture(1)
+            for i in range(steps):
+                st.step_graph.launch()
     else:
         for i in range(steps):
             one_step(traj[i + 1] if want_trajectory else None)
     if not want_trajectory:
         traj[1].copy_(y)
-    return traj
+    # the state's buffers are rewritten by this thread's next call: hand back a copy (6 MB at C2, a few us)
+    return traj.clone() if persistent else traj
+
+
+# F5E_LOOP_GRAPH=0: keep replaying the one-step graph (A/B switch for the whole-loop graph)
+LOOP_GRAPH = os.environ.get("F5E_LOOP_GRAPH", "1") != "0"

@@ -285,31 +285,48 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
 
-    def process_batch(gen_text):
+    def process_batch(gen_text, seed=None):
+        """Queues one chunk on the GPU and returns DEVICE tensors: nothing here waits for the GPU, so the host prep of
+        the next chunk overlaps this chunk's ODE loop; the caller copies to the host afterwards."""
         text_list = convert_char_to_pinyin([ref_text + gen_text])
         ref_audio_len = audio.shape[-1] // hop_length
         duration, _ = plan_batch(ref_audio_len, ref_text, gen_text, speed, fix_duration)
         with torch.inference_mode():
             generated, _traj = model_obj.sample(cond=audio, text=text_list, duration=duration, steps=nfe_step,
-                                                cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
+                                                cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
+                                                seed=seed)
             del _traj
             generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
             wave_ = vocoder.decode(generated)
             if rms < target_rms:
                 wave_ = wave_ * rms / target_rms
-            return wave_.squeeze().cpu().numpy(), generated[0].cpu().numpy()
+            return wave_, generated
+
+    def to_host(res):
+        wave_, generated = res
+        return wave_.squeeze().cpu().numpy(), generated[0].cpu().numpy()
 
     if streaming:
         for gen_text in gen_text_batches:
-            w, _ = process_batch(gen_text)
+            w, _ = to_host(process_batch(gen_text))
             for j in range(0, len(w), chunk_size):
                 yield w[j: j + chunk_size], target_sample_rate
         return
-    # the reference fans chunks out to a thread pool on ONE model (utils_infer.py:511); the engine keeps every
-    # per-call buffer private to the call and captures on a per-thread stream, so that is safe here (SURVEY F12,
-    # tests/test_e2e_gpu.py::test_concurrent_sample_calls_from_two_threads)
-    with ThreadPoolExecutor() as ex:
-        results = list(ex.map(process_batch, gen_text_batches))
+    # The reference submits process_batch to a ThreadPoolExecutor (utils_infer.py:511), but process_batch is a generator
+    # function there: submit() only creates the generator, and the chunks then run ONE AT A TIME, in order, in the consumer
+    # loop (`next(result)`, :514-518).  Default here = the same order on the calling thread, so with seed=None the noise
+    # of chunk i is the i-th draw from the global CPU generator exactly as in the reference (reproducible under
+    # torch.manual_seed); the GPU still overlaps chunks with the host because nothing above waits for it.
+    # F5E_INFER_WORKERS=k (2..4) opts into k host threads, each with its own capture stream (SURVEY F12; the engine keeps
+    # per-call buffers private per thread): more throughput on one GPU, and a per-chunk seed drawn in submission order on
+    # this thread keeps the result independent of thread timing (a different noise stream than the serial default).
+    workers = max(1, min(4, int(os.environ.get("F5E_INFER_WORKERS", "1"))))
+    if workers == 1 or len(gen_text_batches) < 2:
+        results = [to_host(r) for r in [process_batch(g) for g in gen_text_batches]]
+    else:
+        seeds = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) for _ in gen_text_batches]
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            results = list(ex.map(lambda a: to_host(process_batch(*a)), zip(gen_text_batches, seeds)))
     waves = [r[0] for r in results]
     specs = [r[1] for r in results]
     if waves:

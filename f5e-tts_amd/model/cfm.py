@@ -90,6 +90,11 @@ class CFM(nn.Module):
             dur_h = duration.detach().to("cpu", torch.long)
         if text is not None:
             text_h = text.detach().to("cpu")
+            rows = getattr(getattr(self.transformer, "text_embed", None), "text_embed", None)
+            if rows is not None and text_h.numel() and int(text_h.max()) + 1 >= rows.num_embeddings:
+                # nn.Embedding raises here in the reference (vocab file / checkpoint mismatch); the HIP gather would clamp
+                raise IndexError(f"token id {int(text_h.max())} out of range for a text embedding of "
+                                 f"{rows.num_embeddings} rows (ids are shifted by +1, backbones/dit.py:55)")
             dur_h = torch.maximum(torch.maximum((text_h != -1).sum(dim=-1), lens_h) + 1, dur_h)
             text = h2d(text, dv)
         else:
@@ -105,7 +110,10 @@ class CFM(nn.Module):
         if edit_mask is not None:
             cond_mask = h2d(cond_mask, dv) & edit_mask.to(dv)
         cond_mask = h2d(F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False), dv).unsqueeze(-1)
-        step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond)).contiguous()
+        from .. import ops
+        cond = cond.contiguous()
+        step_cond = ops.stitch(cond, torch.zeros_like(cond), cond_mask.reshape(-1).to(torch.uint8).contiguous(),
+                               torch.empty_like(cond))    # where(cond_mask, cond, 0), cfm.py:423
         seq_len = dur_h.to(I32) if batch > 1 else None  # reference: mask = None for single inference (cfm.py:425-428)
         # seeded noise, one item at a time, CPU generator (cfm.py:452-457)
         y0 = torch.zeros(batch, n, self.num_channels, dtype=F32)
@@ -122,7 +130,7 @@ class CFM(nn.Module):
         t_start = 0
         if duplicate_test:
             t_start = t_inter
-            y0 = (1 - t_start) * y0 + t_start * test_cond
+            y0 = ops.axpby(y0, test_cond.contiguous(), torch.empty_like(y0), 1 - t_start, t_start)   # cfm.py:463
             steps = int(steps * (1 - t_start))
         t = torch.linspace(t_start, 1, steps + 1, dtype=F32)
         if sway_sampling_coef is not None:
@@ -145,8 +153,6 @@ class CFM(nn.Module):
             with torch.cuda.stream(side):
                 trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup)
             cur.wait_stream(side)
-            if setup.get("graph") is not None:
-                setup.pop("graph").retire()   # event on the caller's stream (behind the wait): safe to poll from any thread
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)
         self.transformer.clear_cache()

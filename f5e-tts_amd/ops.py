@@ -284,7 +284,7 @@ def text_gather(ids: Tensor, table: Tensor, pos: Optional[Tensor], keep: Optiona
     B, N, TD = out.shape
     check(lib().f5e_text_gather(_stream(), _p(ids, I32, "ids"), _p(table, F32, "table"), _p(pos, F32, "pos"),
                                 _p(keep, F32, "keep"), _p(out, F32, "out"), B, N, TD,
-                                pos.shape[0] if pos is not None else 1), "f5e_text_gather")
+                                pos.shape[0] if pos is not None else 1, table.shape[0]), "f5e_text_gather")
     return out
 
 
@@ -317,6 +317,22 @@ def stitch(cond: Tensor, y: Tensor, mask_u8: Tensor, out: Tensor):
 def cast_bf16(x: Tensor, out: Tensor):
     require_device()
     check(lib().f5e_cast_bf16(_stream(), _p(x, F32, "x"), _p(out, BF, "out"), x.numel()), "f5e_cast_bf16")
+    return out
+
+
+def cast_f32(x: Tensor, out: Tensor):
+    require_device()
+    check(lib().f5e_cast_f32(_stream(), _p(x, BF, "x"), _p(out, F32, "out"), x.numel()), "f5e_cast_f32")
+    return out
+
+
+def axpby(x: Tensor, y: Optional[Tensor], out: Tensor, a: float = 1.0, b: float = 1.0, c: float = 0.0):
+    """out = a x + b y + c (y optional), f32 contiguous tensors of equal size."""
+    require_device()
+    if y is not None and y.numel() != x.numel() or out.numel() != x.numel():
+        raise _C.F5EError("axpby: size mismatch")
+    check(lib().f5e_axpby(_stream(), _p(x, F32, "x"), _p(y, F32, "y"), _p(out, F32, "out"), a, b, c, x.numel()),
+          "f5e_axpby")
     return out
 
 
@@ -375,8 +391,9 @@ class Graph:
     @staticmethod
     def reap():
         with Graph._parked_lock:
-            done = [x for x in Graph._parked if x[1].query()]
-            Graph._parked[:] = [x for x in Graph._parked if not x[1].query()]
+            state = [(x, x[1].query()) for x in Graph._parked]    # ONE query per event: it may complete in between
+            done = [x for x, finished in state if finished]
+            Graph._parked[:] = [x for x, finished in state if not finished]
         for g, _ in done:
             g.destroy()
 

@@ -168,9 +168,11 @@ int f5e_im2col(f5e_stream st, const float* x, float* col, int B, int T, int Cin,
 int f5e_sinus_embed(f5e_stream st, const float* t, const float* freqs, float* out, int E, int dim, float scale);
 /* out[n][i] = (cos, sin)(n * inv_freq[i])   (x_transformers RotaryEmbedding.forward_from_seq_len) */
 int f5e_rope_table(f5e_stream st, const float* inv_freq, float* out, int N, int half);
-/* out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]   (backbones/dit.py:68-80) */
+/* out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]   (backbones/dit.py:68-80).  table f32
+ * [table_rows][TD]; an id outside [0, table_rows) is clamped (nn.Embedding raises IndexError there: the host side checks
+ * ids that start on the host, the clamp only keeps device-resident garbage from reading outside the table). */
 int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const float* pos, const float* keep, float* out,
-                    int B, int N, int TD, int max_pos);
+                    int B, int N, int TD, int max_pos, int table_rows);
 /* v = p0 | p0 + (p0 - p1) w0 | w0 (p2 - p1) + w1 (p1 - p0) + p0   (mode 0 | 1 | 2; p_k = pred + k * branch_stride);
  * dst = base + coef[*eval_ptr] * v; traj (optional) gets a copy.   (model/cfm.py:447, :187, :310 + Euler/midpoint)
  * done_ctr (optional, one zero-initialised u32): the last workgroup to finish does ++*eval_ptr and re-zeroes it. */
@@ -187,6 +189,10 @@ int f5e_advance_eval(f5e_stream st, int* eval_ptr);
 int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
                int C);
 int f5e_cast_bf16(f5e_stream st, const float* x, void* y, long long n);
+/* y f32 = x bf16 (exact).  Used to rebuild the fused-AdaLN tables from the bf16 weights the MFMA kernels read. */
+int f5e_cast_f32(f5e_stream st, const void* x, float* y, long long n);
+/* out = a x + b y + c  (y may be NULL).  (1 - t_inter) y0 + t_inter cond of duplicate_test (model/cfm.py:460-465). */
+int f5e_axpby(f5e_stream st, const float* x, const float* y, float* out, float a, float b, float c, long long n);
 /* GumbelVectorQuantizer eval forward (model/modules.py:881-950): logits f32 [rows][ld] (groups * num_vars used) ->
  * targets i32 [rows][groups] (first maximal index), out f32 [rows][groups * var_dim] gathered from vars f32
  * [(combine_groups ? 1 : groups) * num_vars][var_dim]; stats (optional) f32[2] = (code_perplexity, prob_perplexity). */
@@ -250,6 +256,21 @@ typedef struct f5e_dit_plan {
   int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
 } f5e_dit_plan;
 
+/* Workspace planner (SURVEY 8b lower side): byte size and 256-byte-aligned offset of every caller-owned buffer of
+ * f5e_dit_plan inside ONE arena of `total` bytes.  Only the shape fields of `shape` are read (S, N, D, H, FF, mel, fuse_ln
+ * and whether w_skip is set); n_pad = N rounded up to 64 is what the plan must carry.  Buffers that the shape does not
+ * need (ln_stats without fuse_ln, skip_* without w_skip) get size 0.  q, k and vt must be zero-filled once by the caller
+ * (their pad rows are never written).  Host call, no kernel launch, no allocation. */
+enum { F5E_WS_H0 = 0, F5E_WS_H0_BF16, F5E_WS_C1, F5E_WS_X, F5E_WS_HN, F5E_WS_Q, F5E_WS_K, F5E_WS_VT, F5E_WS_AO, F5E_WS_FF,
+       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_COUNT };
+typedef struct f5e_dit_workspace {
+  int n_pad;
+  unsigned long long bytes[F5E_WS_COUNT];
+  unsigned long long offset[F5E_WS_COUNT];
+  unsigned long long total;
+} f5e_dit_workspace;
+int f5e_workspace_bytes(const f5e_dit_plan* shape, f5e_dit_workspace* out_host);
+
 enum { F5E_OP_NONE = 0, F5E_OP_INPROJ = 1, F5E_OP_CONVPOS = 2, F5E_OP_LN = 3, F5E_OP_QKV = 4, F5E_OP_ATTN = 5,
        F5E_OP_OUT = 6, F5E_OP_FF1 = 7, F5E_OP_FF2 = 8, F5E_OP_FINAL = 9 };
 
@@ -260,11 +281,12 @@ int f5e_timer_destroy(void* timer);
 int f5e_timer_reset(void* timer);
 int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
 
-/* Diagnostics (tools/convpos_time.py): while buf != NULL, f5e_convpos / f5e_convpos_ln launch a build of their kernels
- * that writes 8 timestamps per workgroup ([groups * tiles * S][8] uint64: s_memrealtime at entry, s_memtime at entry,
- * first tile landed, two marks inside the tap loop, loop done, stores acknowledged, s_memrealtime at exit).  Process-wide,
- * not for concurrent callers. */
+#ifdef F5E_TOOLS
+/* Diagnostics, TOOLS build only (make -C f5e-tts_amd/csrc tools-lib -> libf5e_hip_tools.so; tools/convpos_time.py): while
+ * buf != NULL, f5e_convpos / f5e_convpos_ln launch a build of their kernels that writes 8 timestamps per workgroup.  This is
+ * process-wide mutable state, which is why the shipped libf5e_hip.so neither contains nor exports it. */
 void f5e_debug_convpos_trace(void* buf);
+#endif
 
 /* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
 int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import f5e_oracle as O
+from tools import synth as SY
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +20,7 @@ def rel_l2(a, b):
 
 def build(cfg: O.DiTConfig, seed=1234):
     from f5e_tts_amd.model import CFM, DiT
-    sd = O.init_dit_state(cfg, seed)
+    sd = SY.init_dit_state(cfg, seed)
     ppg_config = dict(use_ppg=cfg.use_ppg, ppg_dim=cfg.ppg_dim, use_transformer=False)
     dit = DiT(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=64, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
               text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, text_mask_padding=cfg.text_mask_padding,
@@ -81,8 +82,8 @@ def test_batch_invariance_across_gemm_paths_full_model():
     cfg = O.DiTConfig()
     sd, dit, cfm = build(cfg)
     B, N_ref, N = 7, 375, 938
-    wav = O.synthetic_ref_wave(N_ref, batch=B).cuda()
-    text = O.synthetic_text_ids(N, batch=B)
+    wav = SY.synthetic_ref_wave(N_ref, batch=B).cuda()
+    text = SY.synthetic_text_ids(N, batch=B)
     kw = dict(duration=N, steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=4)
     full, _ = cfm.sample(wav, text, **kw)
     assert torch.isfinite(full).all()
@@ -96,7 +97,7 @@ def test_batch_invariance_across_gemm_paths_full_model():
 def test_ditblock_api():
     from f5e_tts_amd.model import DiTBlock
     cfg = O.DiTConfig(**SMALL)
-    sd = O.init_dit_state(cfg, 77)
+    sd = SY.init_dit_state(cfg, 77)
     blk = DiTBlock(dim=1024, heads=16, dim_head=64, ff_mult=2)
     blk.load_state_dict({k[len("transformer_blocks.0."):]: v for k, v in sd.items()
                          if k.startswith("transformer_blocks.0.")})
@@ -114,12 +115,12 @@ def test_ditblock_api():
 def test_melspec_and_vocos():
     from f5e_tts_amd.model import MelSpec
     from f5e_tts_amd.vocoder import Vocos
-    wav = O.synthetic_ref_wave(64, batch=2)
+    wav = SY.synthetic_ref_wave(64, batch=2)
     mel = MelSpec()(wav.cuda())
     ref = O.log_mel_spectrogram(wav)
     assert mel.shape == ref.shape == (2, 100, 64)
     torch.testing.assert_close(mel.cpu(), ref, rtol=1e-4, atol=2e-4)
-    vs = O.init_vocos_state()
+    vs = SY.init_vocos_state()
     voc = Vocos()
     voc.load_state_dict(vs, strict=False)
     voc = voc.cuda().eval()
@@ -136,8 +137,8 @@ def test_cfm_sample_c1_parity(graph):
     cfg = O.DiTConfig()
     sd, dit, cfm = build(cfg)
     cfm.use_graph = graph
-    wav = O.synthetic_ref_wave(188)
-    text = O.synthetic_text_ids(469)
+    wav = SY.synthetic_ref_wave(188)
+    text = SY.synthetic_text_ids(469)
     ref_out, ref_traj = O.cfm_sample(sd, cfg, wav, text, None, 469, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0,
                                      seed=0)
     out, traj = cfm.sample(wav.cuda(), text.cuda(), duration=469, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0,
@@ -414,7 +415,7 @@ def test_infer_cli_end_to_end(tmp_path, ref_sr):
         "head": {"init_args": dict(dim=512, n_fft=1024, hop_length=256, padding="center")}}))
     voc = Vocos()
     torch.save(voc.state_dict(), str(vdir / "pytorch_model.bin"))
-    wav = O.synthetic_ref_wave(190)[0].numpy()
+    wav = SY.synthetic_ref_wave(190)[0].numpy()
     U.save_wav(str(tmp_path / "ref.wav"), wav * 3.0, ref_sr)    # 16 kHz: goes through the sinc resampler
     (tmp_path / "cfg.toml").write_text(f'vocoder_local_path = "{vdir}"\nnfe_step = 4\n')
     infer_cli.main(["-c", str(tmp_path / "cfg.toml"), "-mc", str(tmp_path / "arch.yaml"), "-p",

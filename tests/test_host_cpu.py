@@ -21,6 +21,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "f5e_abi.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef F5E_TOOLS.*?#endif", "", text, flags=re.S)   # diagnostics of the tools build, not shipped
     return sorted(set(re.findall(r"\b(f5e_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -34,6 +35,41 @@ def test_library_exports_every_declared_symbol():
         assert n in _C.SIGNATURES, f"{n} has no ctypes signature"
     assert lib.f5e_abi_version() == 1
     assert lib.f5e_last_error() == b""
+
+
+def test_shipped_library_has_no_debug_hook():
+    """The in-kernel timestamp hook is process-wide mutable state: tools build only (include/f5e_abi.h, F5E_TOOLS)."""
+    from f5e_tts_amd import _C
+    assert not hasattr(_C.lib(), "f5e_debug_convpos_trace")
+
+
+def test_workspace_bytes_planner():
+    """f5e_workspace_bytes: sizes follow the plan's shape, offsets are 256-byte aligned and disjoint, optional
+    buffers appear only when the shape asks for them.  (engine.make_plan carves exactly this arena: GPU test.)"""
+    import ctypes as C
+    from f5e_tts_amd import _C
+    lib = _C.lib()
+    p, w = _C.DitPlan(), _C.DitWorkspace()
+    p.S, p.B, p.N, p.D, p.H, p.FF, p.L, p.mel, p.mod_rows = 2, 1, 469, 1024, 16, 2048, 22, 100, 1
+    assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == 0
+    M, n_pad = 2 * 469, 512
+    assert w.n_pad == n_pad
+    want = dict(h0=M * 1024 * 4, h0_bf16=M * 1024 * 2, c1=M * 1024 * 2, x=M * 1024 * 4, hn=M * 1024 * 2,
+                q=2 * 16 * n_pad * 64 * 2, k=2 * 16 * n_pad * 64 * 2, vt=2 * 16 * n_pad * 64 * 2, ao=M * 1024 * 2,
+                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0)
+    got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
+    assert got == want
+    end = 0
+    for i in range(len(_C.WS_NAMES)):
+        assert w.offset[i] % 256 == 0 and w.offset[i] >= end
+        end = w.offset[i] + w.bytes[i]
+    assert w.total >= end and w.total % 256 == 0
+    p.fuse_ln, p.w_skip = 1, 8
+    assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == 0
+    got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
+    assert got["ln_stats"] == M * 16 * 2 * 4 and got["skip_res"] == got["skip_tmp"] == M * 1024 * 4
+    p.N = 0
+    assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == -1 and b"workspace_bytes" in lib.f5e_last_error()
 
 
 def test_abi_rejects_bad_shapes_without_launching():

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import f5e_oracle as O
+from tools import synth as SY
 
 pytestmark = pytest.mark.gpu
 
@@ -360,7 +361,7 @@ def fft_tables():
 
 @pytest.mark.parametrize("B,frames", [(1, 188), (3, 21)])
 def test_stft_logmel(ops, B, frames):
-    wav = O.synthetic_ref_wave(frames, batch=B)
+    wav = SY.synthetic_ref_wave(frames, batch=B)
     win, tw = fft_tables()
     out = torch.empty(B, frames, 100, device="cuda")
     ops.stft_logmel(dev(wav), dev(win), dev(tw), dev(O.mel_filterbank_htk()), out, 1024, 256)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import f5e_oracle as O
+from tools import synth as SY
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = ["b1", "b2_mask", "b1_midpoint", "b2_ppg_tts", "b1_ppg_vc"]
@@ -96,13 +97,13 @@ def test_sample_prep_matches_reference():
 
 def test_mel_and_istft_third_party_crosschecks():
     """torchaudio / vocos arithmetic is 'parity unpinned'; cross-check structure with torch.stft/istft only."""
-    w = O.synthetic_ref_wave(20)
+    w = SY.synthetic_ref_wave(20)
     assert w.shape[-1] // 256 + 1 == 20
     mel = O.log_mel_spectrogram(w)
     assert mel.shape == (1, 100, 20)
     fb = O.mel_filterbank_htk()
     assert fb.shape == (513, 100) and float(fb.min()) >= 0 and float(fb.sum(0).min()) > 0
-    vs = O.init_vocos_state()
+    vs = SY.init_vocos_state()
     wav = O.vocos_decode(vs, mel)
     assert wav.shape == (1, 256 * 19)
     assert torch.isfinite(wav).all()

@@ -3,12 +3,12 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import f5e_oracle as O
+from tools import synth as SY
 from f5e_tts_amd.model import CFM, DiT
-cfg = O.DiTConfig(); sd = O.init_dit_state(cfg, 1234)
+cfg = SY.DiTConfig(); sd = SY.init_dit_state(cfg, 1234)
 dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
 dit.load_state_dict(sd); cfm = CFM(transformer=dit).cuda().eval()
-wav = O.synthetic_ref_wave(188).cuda(); text = O.synthetic_text_ids(469)
+wav = SY.synthetic_ref_wave(188).cuda(); text = SY.synthetic_text_ids(469)
 for cfgs in (2.0, 0.0, 2.0, 0.0):
     kw = dict(duration=469, steps=32, cfg_strength=cfgs, sway_sampling_coef=-1.0, seed=0)
     for _ in range(2): cfm.sample(wav, text, **kw)

@@ -5,15 +5,15 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
 import torch
-from oracle import f5e_oracle as O
+from tools import synth as SY
 from f5e_tts_amd.model import CFM, DiT
 from f5e_tts_amd.vocoder import Vocos
 
-cfg = O.DiTConfig(); sd = O.init_dit_state(cfg, 1234)
+cfg = SY.DiTConfig(); sd = SY.init_dit_state(cfg, 1234)
 dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
 dit.load_state_dict(sd); cfm = CFM(transformer=dit).cuda().eval()
-voc = Vocos(); voc.load_state_dict(O.init_vocos_state(), strict=False); voc = voc.cuda().eval()
-wav = O.synthetic_ref_wave(188).cuda(); text = O.synthetic_text_ids(469)
+voc = Vocos(); voc.load_state_dict(SY.init_vocos_state(), strict=False); voc = voc.cuda().eval()
+wav = SY.synthetic_ref_wave(188).cuda(); text = SY.synthetic_text_ids(469)
 
 def one(_):
     mel, _t = cfm.sample(wav, text, duration=469, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)

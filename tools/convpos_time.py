@@ -56,7 +56,9 @@ with torch.cuda.stream(st):
         tiles = (N + 63) // 64
         nwg = G * tiles * S
         buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+        # the hook exists in the TOOLS build only: make -C f5e-tts_amd/csrc tools-lib; F5E_HIP_LIB=.../libf5e_hip_tools.so
         hook = _C.lib().f5e_debug_convpos_trace
+        hook.argtypes, hook.restype = [ctypes.c_void_p], None
         hook(ctypes.c_void_p(buf.data_ptr()))
         for i in range(6):  # last launch is what stays in the buffer
             ops.convpos(x, wps[(2 * i) % NW], b, S, N, out_bf16=c1)

@@ -4,11 +4,11 @@ import os, sys, time, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from f5e_tts_amd.model import CFM, DiT
-from oracle import f5e_oracle as O
-cfg = O.DiTConfig(); sd = O.init_dit_state(cfg, 1234)
+from tools import synth as SY
+cfg = SY.DiTConfig(); sd = SY.init_dit_state(cfg, 1234)
 dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
 dit.load_state_dict(sd); cfm = CFM(transformer=dit).cuda().eval()
-wav = O.synthetic_ref_wave(188).cuda(); text = O.synthetic_text_ids(469).cuda()
+wav = SY.synthetic_ref_wave(188).cuda(); text = SY.synthetic_text_ids(469).cuda()
 kw = dict(duration=469, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
 for _ in range(3): cfm.sample(wav, text, **kw)
 torch.cuda.synchronize()

@@ -5,12 +5,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
 import torch
-from oracle import f5e_oracle as O
+from tools import synth as SY
 from f5e_tts_amd.model import CFM, DiT
 
 KW = dict(dim=1024, depth=2, heads=16, ff_mult=2, text_dim=256, conv_layers=2, text_num_embeds=300)
-cfg = O.DiTConfig(**KW)
-sd = O.init_dit_state(cfg, 1234)
+cfg = SY.DiTConfig(**KW)
+sd = SY.init_dit_state(cfg, 1234)
 dit = DiT(**KW)
 dit.load_state_dict(sd)
 cfm = CFM(transformer=dit).cuda().eval()
