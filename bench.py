@@ -12,13 +12,19 @@ sway -1, seeded random-init weights (AdaLN-zero tensors re-randomised, SURVEY F8
 Inputs are resident in HBM when the timed region starts; outputs stay on the device.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (QKV/FF bf16 MFMA GEMM class chosen by total time) timed per launch with HIP
-                  events on the launch stream during an eager, in-situ pass of the same workload;
-  cpu_baseline -- the CPU oracle ("port") on a bounded sample of the same workload on this box's host cores.
+  roofline       -- the dominant kernel of the workload (bf16 MFMA GEMM class chosen by total time) timed per launch with
+                    HIP events on the launch stream during an eager, in-situ pass of the same workload; `traffic` from the
+                    committed rocprofv3 --pmc summary, only when it was measured on the kernel sources that run here;
+  roofline_c3    -- (default C2 run, 1 GPU) one pass of BASELINE config C3 (batch 32 x 10 s) with the same in-situ timer on
+                    the four block GEMMs and attention: per-op us / TFLOP/s / fraction of the 2.5 PFLOP/s dense bf16 peak
+                    and the flop-weighted fraction the north star's ">= 40 % MFMA on attention + MLP GEMMs" refers to;
+  cpu_baseline   -- the CPU oracle ("port") on the same workload on this box's host cores: 1 warm-up + median of 3;
+  parity_rel_l2  -- relative L2 of the GPU mel of the timed workload against the oracle's mel (the warm-up run above).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,10 +35,15 @@ if ROOT not in sys.path:
 N_REF, N_TOTAL, NFE, CFG, SWAY = 188, 469, 32, 2.0, -1.0
 BATCH = 1
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+D_MODEL, FF_DIM, HEADS = 1024, 2048, 16
 
 
-def gemm_flops(op, M, D=1024, FF=2048):
-    return {"QKV": 2.0 * M * D * 3 * D, "OUT": 2.0 * M * D * D, "FF1": 2.0 * M * D * FF, "FF2": 2.0 * M * FF * D}[op]
+def op_flops(op, M, n_seq=None, n_frames=None):
+    """Algorithmic FLOP of one launch: 2 M N K for the block linears, 4 N^2 64 H per sequence for attention."""
+    if op == "ATTN":
+        return 4.0 * n_frames * n_frames * 64 * HEADS * n_seq
+    return {"QKV": 2.0 * M * D_MODEL * 3 * D_MODEL, "OUT": 2.0 * M * D_MODEL * D_MODEL,
+            "FF1": 2.0 * M * D_MODEL * FF_DIM, "FF2": 2.0 * M * FF_DIM * D_MODEL}[op]
 
 
 def log(msg):
@@ -49,6 +60,29 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def host_cpu_info():
+    """Model name and physical core count of the host (lscpu), for the cpu_baseline record."""
+    info = {"model": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in out.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        if "Core(s) per socket" in kv and "Socket(s)" in kv:
+            info["physical_cores"] = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:
+        pass
+    return info
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,10 +90,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the roofline_c3 leg of the default run")
     ap.add_argument("--streams", type=int, default=4,
                     help="extra leg (1 GPU only, reported as `concurrent`, never as `value`): this many host threads sample "
-                         "batch-1 utterances concurrently on one model, as the reference's infer_batch_process does "
-                         "with its ThreadPoolExecutor; 0 skips it")
+                         "batch-1 utterances concurrently on one model; 0 skips it")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"],
                     help="C2 (default, the graded line): batch 1, 2 s ref / 5 s total; C3: batch 32, 4 s / 10 s; "
                          "C4: eval_infer_batch-style stream of single utterances (LibriSpeech-PC length mix, NFE 16, "
@@ -84,31 +118,35 @@ def main():
     # host-side prep (seeded noise, masks, token ids) is a few tiny CPU ops per pass: keep every rank on a small, fixed
     # number of threads so 8 ranks on one node do not oversubscribe the host with OpenMP teams
     torch.set_num_threads(max(1, min(4, host_threads() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
+    backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL writes its banner / warnings to stdout: send them to a file so stdout carries exactly one JSON line
         os.environ["NCCL_DEBUG"] = os.environ.get("F5E_NCCL_DEBUG", "WARN")
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/f5e_rccl_%h_%p.log")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))  # RCCL on ROCm
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world
 
     from f5e_tts_amd import ops
-    from f5e_tts_amd._C import OP_FF1, OP_FF2, OP_OUT, OP_QKV
+    from f5e_tts_amd._C import OP_ATTN, OP_FF1, OP_FF2, OP_OUT, OP_QKV
     from f5e_tts_amd.engine import KernelTimer
     from f5e_tts_amd.model import CFM, DiT
     from f5e_tts_amd.vocoder import Vocos
-    from oracle import f5e_oracle as O  # only for seeded synthetic inputs/weights and the cpu_baseline leg
+    from tools import synth as SY   # seeded synthetic weights / inputs (neutral module: not the oracle, not the product)
 
     ops.require_device()
     if args.workload == "C5":   # BASELINE config 5: configs/F5TTS_Small_PPG.yaml (dim 768, 18 blocks, PPG input)
-        cfg = O.DiTConfig(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
-                          text_mask_padding=False, pe_attn_head=1, use_ppg=True, ppg_dim=256)
+        cfg = SY.DiTConfig(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
+                           text_mask_padding=False, pe_attn_head=1, use_ppg=True, ppg_dim=256)
         ppg_config = dict(use_ppg=True, ppg_dim=256, use_transformer=False)
         dit = DiT(dim=768, depth=18, heads=12, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545,
                   text_mask_padding=False, pe_attn_head=1, ppg_config=ppg_config)
-        dit.load_state_dict(SY.init_dit_state(cfg, 1234), strict=True)
+        sd = SY.init_dit_state(cfg, 1234)
+        dit.load_state_dict(sd, strict=True)
         cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
     else:
-        cfg = O.DiTConfig()
+        cfg = SY.DiTConfig()
         sd = SY.init_dit_state(cfg, 1234)
         dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
         dit.load_state_dict(sd, strict=True)
@@ -119,9 +157,11 @@ def main():
     voc = voc.cuda().eval()
     wav = SY.synthetic_ref_wave(N_REF, batch=BATCH).cuda()
     text = SY.synthetic_text_ids(N_TOTAL, batch=BATCH)   # token ids stay on the host, as the reference's callers hand them
+    last_mel = [None]
 
     def one_pass():
         mel, _ = cfm.sample(wav, text, duration=N_TOTAL, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+        last_mel[0] = mel
         return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
 
     step_frames = None       # per-step (total, generated) frame counts when the steps differ (C4)
@@ -132,19 +172,12 @@ def main():
         def one_pass():  # noqa: F811  reference eval_infer_batch_vc.py:214-224 (alpha_spk 2.5, alpha_ppg 3)
             mel, _ = cfm.sample_vc(wav, ppg, duration=N_TOTAL, steps=NFE, alpha_spk=2.5, alpha_ppg=3.0,
                                    sway_sampling_coef=SWAY, seed=0)
+            last_mel[0] = mel
             return voc.decode(mel[:, N_REF:, :].permute(0, 2, 1))
     if args.workload == "C4":
-        from f5e_tts_amd.eval.eval_infer_batch import flop_fwd, lpt_partition
-        utts = []
-        with open(os.path.join(ROOT, "tests", "golden", "c4_durations.csv")) as f:
-            for line in f:
-                if line.startswith("#"):
-                    continue
-                rs, rb, _gs, gb = line.split(",")
-                ref_len = int(float(rs) * 24000) // 256
-                utts.append((ref_len, ref_len + int(ref_len / (int(rb) + 1) * int(gb))))   # utils_eval.py:337-339
+        from f5e_tts_amd.eval.eval_infer_batch import c4_work_list, flop_fwd, lpt_partition
         need = world * (args.steps + args.warmup)
-        utts = [utts[i % len(utts)] for i in range(need)]
+        utts = c4_work_list(os.path.join(ROOT, "tests", "golden", "c4_durations.csv"), need)
         mine = [utts[i] for i in lpt_partition([flop_fwd(t) for _, t in utts], world)[rank]]
         inputs = [(SY.synthetic_ref_wave(r).cuda(), SY.synthetic_text_ids(t), r, t) for r, t in mine]
         step_frames = [(t, t - r) for _, _, r, t in inputs[args.warmup:]]
@@ -179,6 +212,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gpu_mel = last_mel[0].detach().clone() if last_mel[0] is not None else None
     # the timed passes are queued back to back (host prep of pass i+1 overlaps the ODE loop of pass i): same inputs and
     # seed, so the last of them must reproduce the isolated, synchronised warm-up pass bit for bit
     pipelined_ok = None
@@ -186,11 +220,6 @@ def main():
         pipelined_ok = bool(torch.equal(last_out, isolated_out))
     if pipelined_ok is False:
         raise SystemExit("bench: pipelined pass differs from the isolated pass")
-    if distributed:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
     # Concurrency leg: the batch-1 chain is latency-bound, so independent utterances in flight on separate
@@ -200,7 +229,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         n_conc = -(-max(args.steps, 8 * args.streams) // args.streams) * args.streams   # a whole number of rounds
         with ThreadPoolExecutor(max_workers=args.streams) as ex:
-            list(ex.map(lambda _: one_pass(), range(args.streams)))      # per-thread stream / graph warm-up
+            list(ex.map(lambda _: one_pass(), range(2 * args.streams)))      # per-thread stream / graph warm-up
             torch.cuda.synchronize()
             tc = time.perf_counter()
             outs = list(ex.map(lambda _: one_pass(), range(n_conc)))
@@ -214,83 +243,161 @@ def main():
                       "bit_identical_to_sequential": same}
         log(f"concurrent leg: {args.streams} threads, {n_conc} passes in {dtc:.3f} s")
         del outs
-    frames = world * args.steps * N_TOTAL * BATCH
-    gen_frames = world * args.steps * BATCH * (N_TOTAL - N_REF)
+    # whole-job totals: SUM of frames, MAX of wall time over the ranks (RCCL, a few dozen bytes, after the timed region)
+    from f5e_tts_amd.eval.eval_infer_batch import reduce_job_totals
+    my_frames = args.steps * N_TOTAL * BATCH
+    my_gen = args.steps * BATCH * (N_TOTAL - N_REF)
     if step_frames is not None:   # C4: every rank ran its own utterances
-        tt = torch.tensor([sum(a for a, _ in step_frames[:args.steps]), sum(b for _, b in step_frames[:args.steps])],
-                          device="cuda", dtype=torch.float64)
-        if distributed:
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        frames, gen_frames = int(tt[0].item()), int(tt[1].item())
+        my_frames = sum(a for a, _ in step_frames[:args.steps])
+        my_gen = sum(b for _, b in step_frames[:args.steps])
+    red = reduce_job_totals(dist if distributed else None, my_frames, my_gen, elapsed, "cuda")
+    frames, gen_frames, elapsed = int(red["frames"]), int(red["gen_frames"]), red["seconds"]
+    rank_frames, rank_seconds = [int(x) for x in red["per_rank_frames"]], red["per_rank_seconds"]
     gen_audio_s = gen_frames * 256 / 24000.0
     value = frames / elapsed
 
+    OPS = (("QKV", OP_QKV), ("ATTN", OP_ATTN), ("OUT", OP_OUT), ("FF1", OP_FF1), ("FF2", OP_FF2))
+    KERNEL_OF = {"QKV": "gemm_bf16*<EPI_QKV_ROPE>", "OUT": "gemm_bf16*<EPI_GATE_RES>", "FF1": "gemm_bf16*<EPI_BF16_GELU>",
+                 "FF2": "gemm_bf16*<EPI_GATE_RES>", "ATTN": "attn_fwd*"}
+
+    def timed_eager_pass(run, n_rows, n_seq, n_frames, nfe, depth=22):
+        """One eager pass of `run` with HIP events around every launch of the five block op classes (in situ, on the launch
+        stream) -> {op: dict(us median / mean, launches, TFLOP/s, frac)}."""
+        tm = KernelTimer([op for _, op in OPS], capacity=nfe * depth * len(OPS) + 16)
+        cfm.use_graph, cfm.kernel_timer = False, tm
+        try:
+            run()
+            torch.cuda.synchronize()
+            by = tm.read_by_op()
+        finally:
+            cfm.use_graph, cfm.kernel_timer = True, None
+        out = {}
+        for name, op in OPS:
+            ms = by.get(op, [])
+            if not ms:
+                continue
+            med, mean = median(ms), sum(ms) / len(ms)
+            fl = op_flops(name, n_rows, n_seq, n_frames)
+            out[name] = {"us": round(med * 1e3, 2), "mean_us": round(mean * 1e3, 2), "launches": len(ms),
+                         "flop_per_launch": fl, "tflops": round(fl / (med * 1e-3) / 1e12, 1),
+                         "frac": round(fl / (med * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        return out
+
+    def weighted(per, names):
+        fl = sum(per[k]["flop_per_launch"] * per[k]["launches"] for k in names if k in per)
+        tm_ = sum(per[k]["us"] * 1e-6 * per[k]["launches"] for k in names if k in per)
+        return round(fl / tm_ / 1e12 / PEAK_BF16_TFLOPS, 4) if tm_ > 0 else None
+
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # in-situ per-launch timing: eager launches of the SAME kernels in the SAME order, one op class at a time
+        # in-situ per-launch timing: eager launches of the SAME kernels in the SAME order
         n_chains = getattr(dit.engine(), "last_n_chains", 1)
         M = 2 * N_TOTAL * BATCH // n_chains          # rows per launch (the CFG branches may run as parallel chains)
-        cfm.use_graph = False
-        per_op = {}
-        for name, op in (("QKV", OP_QKV), ("OUT", OP_OUT), ("FF1", OP_FF1), ("FF2", OP_FF2)):
-            tm = KernelTimer(op, capacity=NFE * 22 * n_chains + 8)
-            cfm.kernel_timer = tm
-            one_pass()
-            torch.cuda.synchronize()
-            ms = tm.read_ms()
-            ms_sorted = sorted(ms)
-            med = ms_sorted[len(ms) // 2]   # median: an eager pass has host-launch hiccups that inflate the mean
-            per_op[name] = (med, len(ms), sum(ms) / len(ms))
-            log(f"roofline pass {name}: {len(ms)} launches, median {med * 1e3:.1f} us, mean {per_op[name][2] * 1e3:.1f} us")
-        cfm.kernel_timer = None
-        cfm.use_graph = True
-        dom = max(per_op, key=lambda k: per_op[k][0] * per_op[k][1])
-        avg_ms = per_op[dom][0]
-        ach = gemm_flops(dom, M) / (avg_ms * 1e-3) / 1e12
+        per = timed_eager_pass(one_pass, M, 2 * BATCH // n_chains, N_TOTAL, NFE)
+        for k, v in per.items():
+            log(f"roofline pass {k}: {v['launches']} launches, median {v['us']:.1f} us, mean {v['mean_us']:.1f} us")
+        gemms = [k for k in per if k != "ATTN"]
+        dom = max(gemms, key=lambda k: per[k]["us"] * per[k]["launches"])
         # HBM traffic per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
-        # corrected per the microarch guide (tools/pmc_traffic.py); the committed summary is read back here
-        traffic = None
+        # corrected per the microarch guide (tools/pmc_traffic.py).  The committed summary carries the hash of the kernel
+        # sources it was measured on; a summary of other code is refused (traffic = null).
+        traffic, traffic_note = None, "no profiles/pmc_traffic summary"
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload.lower()}.json")
         if os.path.exists(tpath):
             import re
-            epi = {"QKV": 3, "OUT": 2, "FF1": 1, "FF2": 2}[dom]
-            cands = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in json.load(open(tpath))["kernels"].items()
-                     if re.match(rf"gemm_bf16_kernel<\d+, \d+, {epi},", k)]
-            if cands:
-                traffic = max(cands)[1]
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "kernel": {"QKV": "gemm_bf16_kernel<*,*,EPI_QKV_ROPE>", "OUT": "gemm_bf16_kernel<*,*,EPI_GATE_RES>",
-                               "FF1": "gemm_bf16_kernel<*,*,EPI_BF16_GELU>", "FF2": "gemm_bf16_kernel<*,*,EPI_GATE_RES>"}[dom],
-                    "op": dom, "avg_launch_us": round(avg_ms * 1e3, 2), "avg_is": "median of per-launch HIP-event intervals",
-                    "mean_launch_us": round(per_op[dom][2] * 1e3, 2), "launches_timed": per_op[dom][1],
-                    "flop_per_launch": gemm_flops(dom, M), "rows_per_launch": M, "parallel_chains": n_chains,
-                    "all_gemm_avg_us": {k: round(v[0] * 1e3, 2) for k, v in per_op.items()}}
 
-    cpu_baseline = None
+            from tools.src_hash import csrc_sha256
+            tj = json.load(open(tpath))
+            if tj.get("csrc_sha256") != csrc_sha256():
+                traffic_note = "summary was measured on other kernel sources (csrc_sha256 mismatch): refused"
+            else:
+                epi = {"QKV": 3, "OUT": 2, "FF1": 1, "FF2": 2}[dom]
+                cands = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in tj["kernels"].items()
+                         if re.match(rf"gemm_bf16(_pp)?_kernel<(\d+, \d+, )?{epi},", k)]
+                if cands:
+                    traffic, traffic_note = max(cands)[1], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources"
+        d = per[dom]
+        roofline = {"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": d["frac"], "traffic": traffic, "traffic_note": traffic_note,
+                    "kernel": KERNEL_OF[dom], "op": dom, "avg_launch_us": d["us"],
+                    "avg_is": "median of per-launch HIP-event intervals (eager, in situ)",
+                    "mean_launch_us": d["mean_us"], "launches_timed": d["launches"],
+                    "flop_per_launch": d["flop_per_launch"], "rows_per_launch": M, "parallel_chains": n_chains,
+                    "all_ops_us": {k: v["us"] for k, v in per.items()},
+                    "all_ops_frac": {k: v["frac"] for k, v in per.items()},
+                    "gemm_flop_weighted_frac": weighted(per, gemms),
+                    "gemm_attn_flop_weighted_frac": weighted(per, list(per))}
+
+    roofline_c3 = None
+    if (rank == 0 and world == 1 and args.workload == "C2" and not args.no_roofline and not args.no_c3):
+        # BASELINE config C3 (batch 32 x 10 s prompts, NFE 32) is where "MFMA utilisation on the attention + MLP GEMMs" is
+        # defined (SURVEY 8d): one graph pass for its throughput, one eager pass with the in-situ timer for the kernels
+        B3, R3, N3 = 32, 375, 938
+        wav3 = SY.synthetic_ref_wave(R3, batch=B3).cuda()
+        text3 = SY.synthetic_text_ids(N3, batch=B3)
+
+        def c3_pass():
+            mel, _ = cfm.sample(wav3, text3, duration=N3, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+            return voc.decode(mel[:, R3:, :].permute(0, 2, 1))
+
+        c3_pass()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        c3_pass()
+        torch.cuda.synchronize()
+        c3_s = time.perf_counter() - c0
+        per3 = timed_eager_pass(c3_pass, 2 * B3 * N3, 2 * B3, N3, NFE)
+        gem3 = [k for k in per3 if k != "ATTN"]
+        roofline_c3 = {"workload": f"C3: batch {B3}, N_ref={R3} N={N3}, NFE={NFE}, CFG batched ({2 * B3 * N3} rows per launch)",
+                       "mel_frames_per_sec": round(B3 * N3 / c3_s, 1), "pass_ms": round(c3_s * 1e3, 1),
+                       "peak_tflops": PEAK_BF16_TFLOPS,
+                       "ops": {k: {"us": v["us"], "tflops": v["tflops"], "frac": v["frac"], "launches": v["launches"]}
+                               for k, v in per3.items()},
+                       "gemm_flop_weighted_frac": weighted(per3, gem3),
+                       "gemm_attn_flop_weighted_frac": weighted(per3, list(per3)),
+                       "target_frac": 0.40, "timing": "median of per-launch HIP-event intervals, eager in-situ pass"}
+        log(f"roofline_c3: {roofline_c3['mel_frames_per_sec']} mel-frames/s, GEMM frac "
+            f"{roofline_c3['gemm_flop_weighted_frac']}, GEMM+attention {roofline_c3['gemm_attn_flop_weighted_frac']}")
+        del wav3
+
+    cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "C2":
-        sample_steps = NFE  # the full workload once (~15-25 s on 16 host threads)
+        from oracle import f5e_oracle as O   # the checker: parity of the timed workload + the reported CPU baseline
+        ocfg = O.DiTConfig()
         torch.set_num_threads(host_threads())
-        log(f"cpu baseline on {torch.get_num_threads()} threads")
+        cpu = host_cpu_info()
+        log(f"cpu baseline on {torch.get_num_threads()} threads ({cpu['model']}, {cpu['physical_cores']} physical cores)")
         wav_c, text_c = wav.cpu(), text.cpu()
-        with torch.inference_mode():
-            c0 = time.perf_counter()
-            out_c, _ = O.cfm_sample(sd, cfg, wav_c, text_c, None, N_TOTAL, steps=sample_steps, cfg_strength=CFG,
-                                    sway_sampling_coef=SWAY, seed=0)
-            c_loop = time.perf_counter() - c0
-            c1 = time.perf_counter()
-            O.vocos_decode(vs, out_c[:, N_REF:].permute(0, 2, 1))
-            c_voc = time.perf_counter() - c1
-        log(f"cpu baseline: loop sample {c_loop:.2f} s, vocoder {c_voc:.2f} s")
-        est = c_loop * (NFE / sample_steps) + c_voc  # one-off parts (mel, text embed) are < 1% of c_loop
+
+        def cpu_run():
+            with torch.inference_mode():
+                c0 = time.perf_counter()
+                out_c, _ = O.cfm_sample(sd, ocfg, wav_c, text_c, None, N_TOTAL, steps=NFE, cfg_strength=CFG,
+                                        sway_sampling_coef=SWAY, seed=0)
+                c_loop = time.perf_counter() - c0
+                c1 = time.perf_counter()
+                O.vocos_decode(vs, out_c[:, N_REF:].permute(0, 2, 1))
+                return out_c, c_loop, time.perf_counter() - c1
+
+        out_c, wl, wv = cpu_run()                       # warm-up; its mel is the parity reference of the timed workload
+        log(f"cpu warm-up: sample {wl:.2f} s, vocoder {wv:.2f} s")
+        g, r = gpu_mel.float().cpu(), out_c.float()
+        gen = slice(N_REF, N_TOTAL)
+        parity = {"rel_l2_generated": float((g[:, gen] - r[:, gen]).norm() / r[:, gen].norm()),
+                  "rel_l2_full": float((g - r).norm() / r.norm()),
+                  "max_abs": float((g - r).abs().max()), "ref_range": float(r.max() - r.min()),
+                  "tolerance_rel_l2": 1e-2, "against": "oracle fp32 mel of the same C2 workload (NFE 32)"}
+        runs = [cpu_run()[1:] for _ in range(3)]
+        tot = [a + b for a, b in runs]
+        est = median(tot)
+        log("cpu baseline runs: " + ", ".join(f"{t:.2f} s" for t in tot))
         cpu_baseline = {"value": round(N_TOTAL / est, 3), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
-                        "kind": "port",
-                        "sample": f"oracle fp32, the same B=1 N={N_TOTAL} workload once: mel + {sample_steps} Euler steps "
-                                  f"({2 * sample_steps} DiT forwards, {c_loop:.2f} s) + Vocos decode ({c_voc:.2f} s), "
-                                  "no warm-up"}
+                        "kind": "port", "host_cpu": cpu,
+                        "sample": f"oracle fp32, the same B=1 N={N_TOTAL} workload: mel + {NFE} Euler steps ({2 * NFE} DiT "
+                                  f"forwards) + Vocos decode; 1 warm-up + median of 3 ({', '.join(f'{t:.2f}' for t in tot)} s)"}
 
     workload_desc = (f"{args.workload}: F5TTS_v1_Base random-init, batch {BATCH} per GPU, N_ref={N_REF} N={N_TOTAL} frames, "
-                     f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE step, "
+                     f"euler NFE={NFE}, CFG={CFG} (cond+uncond batched), sway={SWAY}, hipGraph ODE loop, "
                      "HIP log-mel front-end + Vocos decode on GPU")
     if args.workload == "C4":
         workload_desc = ("C4: F5TTS_v1_Base random-init, one utterance per call, lengths from the reference's LibriSpeech-PC "
@@ -299,27 +406,36 @@ def main():
     if args.workload == "C5":
         workload_desc = (f"C5: F5TTS_Small + PPG (dim 768, 18 blocks) random-init, batch 1, N_ref={N_REF} N={N_TOTAL} frames, "
                          f"sample_vc (3 branches batched, alpha_spk 2.5, alpha_ppg 3), euler NFE={NFE}, sway={SWAY}, "
-                         "hipGraph ODE step, HIP log-mel + Vocos on GPU")
+                         "hipGraph ODE loop, HIP log-mel + Vocos on GPU")
     if rank == 0:
         line = {
             "metric": "mel_frames_per_sec", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload_desc,
-                       "frames_per_step": (N_TOTAL * BATCH) if step_frames is None else round(frames / (world * args.steps), 1), "parallelism": f"replica x{world} (utterance sharding, no collective "
-                                                                  "on the data path)"},
+                       "frames_per_step": (N_TOTAL * BATCH) if step_frames is None else round(frames / (world * args.steps), 1),
+                       "parallelism": f"replica x{world} (utterance sharding, no collective on the data path)"},
+            "world_size": red["world_size"], "backend": red["backend"],
+            "per_rank_frames": rank_frames, "per_rank_seconds": [round(x, 4) for x in rank_seconds],
             "rtf": round(elapsed / gen_audio_s, 5),
             "isolated_pass_ms": None if latency_ms is None else round(latency_ms, 2),
             "pipelined_equals_isolated": pipelined_ok,
             "generated_mel_frames_per_sec": round(gen_frames / elapsed, 2),
         }
+        if parity is not None:
+            line["parity_rel_l2"] = round(parity["rel_l2_generated"], 6)
+            line["parity"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
         if concurrent is not None:
             line["concurrent"] = concurrent
         if roofline is not None:
             line["roofline"] = roofline
+        if roofline_c3 is not None:
+            line["roofline_c3"] = roofline_c3
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline
         print(json.dumps(line), flush=True)
+    if parity is not None and parity["rel_l2_generated"] > parity["tolerance_rel_l2"]:
+        raise SystemExit(f"bench: GPU mel differs from the oracle: rel L2 {parity['rel_l2_generated']:.3e}")
     if distributed:
         dist.destroy_process_group()
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "f5e_timer_destroy": [_P],
     "f5e_timer_reset": [_P],
     "f5e_timer_read": [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)],
+    "f5e_timer_read_ops": [_P, C.POINTER(C.c_int), _I, C.POINTER(C.c_int)],
     "f5e_graph_begin": [_P],
     "f5e_graph_end": [_P, C.POINTER(C.c_void_p)],
     "f5e_graph_launch": [_P, _P],

@@ -107,11 +107,12 @@ struct F5eTimer {
   int capacity, count;
   hipEvent_t* start;
   hipEvent_t* stop;
+  int* op;  // op class of each recorded pair
 };
 
 int f5e_timer_create(int capacity, void** timer_out) {
   F5E_REQUIRE(capacity > 0 && timer_out, "timer_create: bad arguments");
-  F5eTimer* t = new F5eTimer{capacity, 0, new hipEvent_t[capacity], new hipEvent_t[capacity]};
+  F5eTimer* t = new F5eTimer{capacity, 0, new hipEvent_t[capacity], new hipEvent_t[capacity], new int[capacity]};
   for (int i = 0; i < capacity; ++i) {
     HIP_TRY(hipEventCreate(&t->start[i]), "hipEventCreate");
     HIP_TRY(hipEventCreate(&t->stop[i]), "hipEventCreate");
@@ -129,6 +130,7 @@ int f5e_timer_destroy(void* timer) {
   }
   delete[] t->start;
   delete[] t->stop;
+  delete[] t->op;
   delete t;
   return F5E_OK;
 }
@@ -151,15 +153,26 @@ int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_
   return F5E_OK;
 }
 
+int f5e_timer_read_ops(void* timer, int* ops_out_host, int max_out, int* count_out_host) {
+  F5E_REQUIRE(timer && ops_out_host && count_out_host, "timer_read_ops: null");
+  F5eTimer* t = (F5eTimer*)timer;
+  const int n = t->count < max_out ? t->count : max_out;
+  for (int i = 0; i < n; ++i) ops_out_host[i] = t->op[i];
+  *count_out_host = n;
+  return F5E_OK;
+}
+
 // records a start/stop event pair around `call` when the plan's timer selects this op class (eager launches only)
 #define F5E_TIMED(opclass, call)                                                  \
   do {                                                                            \
-    F5eTimer* tm_ = (p->timer && p->timer_op == (opclass)) ? (F5eTimer*)p->timer : nullptr; \
+    const bool sel_ = p->timer_op >= 0 ? p->timer_op == (opclass) : (((-p->timer_op) >> (opclass)) & 1) != 0; \
+    F5eTimer* tm_ = (p->timer && sel_) ? (F5eTimer*)p->timer : nullptr;          \
     const bool on_ = tm_ && tm_->count < tm_->capacity;                           \
     if (on_) HIP_TRY(hipEventRecord(tm_->start[tm_->count], st), "hipEventRecord"); \
     F5E_TRY(call);                                                                \
     if (on_) {                                                                    \
       HIP_TRY(hipEventRecord(tm_->stop[tm_->count], st), "hipEventRecord");       \
+      tm_->op[tm_->count] = (opclass);                                            \
       tm_->count++;                                                               \
     }                                                                             \
   } while (0)

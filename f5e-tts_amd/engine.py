@@ -451,8 +451,14 @@ class SamplerInputs:
 class KernelTimer:
     """HIP-event pairs recorded by f5e_dit_forward around every launch of one op class (eager launches only)."""
 
-    def __init__(self, op: int, capacity: int = 4096):
+    def __init__(self, op, capacity: int = 4096):
+        """op: one F5E_OP_* class, or a list of classes timed in the same pass (read_by_op)."""
         import ctypes as C
+        if not isinstance(op, int):
+            m = 0
+            for o in op:
+                m |= 1 << int(o)
+            op = -m
         self.op, self.capacity = op, capacity
         self.handle = C.c_void_p()
         _C.check(_C.lib().f5e_timer_create(capacity, C.byref(self.handle)), "f5e_timer_create")
@@ -466,6 +472,18 @@ class KernelTimer:
         cnt = C.c_int(0)
         _C.check(_C.lib().f5e_timer_read(self.handle, buf, self.capacity, C.byref(cnt)), "f5e_timer_read")
         return [buf[i] for i in range(cnt.value)]
+
+    def read_by_op(self) -> Dict[int, List[float]]:
+        """{op class: [ms per launch]} of a multi-class timer."""
+        import ctypes as C
+        ms = self.read_ms()
+        buf = (C.c_int * self.capacity)()
+        cnt = C.c_int(0)
+        _C.check(_C.lib().f5e_timer_read_ops(self.handle, buf, self.capacity, C.byref(cnt)), "f5e_timer_read_ops")
+        out: Dict[int, List[float]] = {}
+        for i in range(min(cnt.value, len(ms))):
+            out.setdefault(int(buf[i]), []).append(ms[i])
+        return out
 
     def __del__(self):
         try:

@@ -82,6 +82,41 @@ def total_mel_len(ref_mel_len: int, prompt_text: str, gt_text: str, speed: float
     return ref_mel_len + int(ref_mel_len / len(prompt_text.encode("utf-8")) * len(gt_text.encode("utf-8")) / speed)
 
 
+def c4_work_list(csv_path: str, need: int) -> List[Tuple[int, int]]:
+    """(ref frames, total frames) of `need` utterances, taken cyclically from a `ref_secs,ref_bytes,gen_secs,gen_bytes`
+    table (tests/golden/c4_durations.csv: the duration / byte-count columns of the reference's LibriSpeech-PC
+    cross-sentence list) with the reference's length rule (eval/utils_eval.py:147-161, prompt text + one space)."""
+    rows = []
+    with open(csv_path) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            rs, rb, _gs, gb = line.split(",")
+            ref_len = int(float(rs) * 24000) // 256
+            rows.append((ref_len, ref_len + int(ref_len / (int(rb) + 1) * int(gb))))
+    return [rows[i % len(rows)] for i in range(need)]
+
+
+def reduce_job_totals(dist, frames: float, gen_frames: float, seconds: float, device="cpu") -> dict:
+    """Whole-job totals of a sharded run: SUM of the frame counts, MAX of the wall time, plus what every rank saw
+    (so that a scaling record can show that `world` ranks really took part).  The only collectives of the path: a few
+    dozen bytes after the timed region.  dist=None -> single process."""
+    if dist is None:
+        return dict(frames=frames, gen_frames=gen_frames, seconds=seconds, per_rank_frames=[frames],
+                    per_rank_seconds=[seconds], world_size=1, backend=None)
+    world = dist.get_world_size()
+    mine = torch.tensor([float(frames), float(gen_frames), float(seconds)], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    tot = mine.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    mx = mine.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return dict(frames=float(tot[0]), gen_frames=float(tot[1]), seconds=float(mx[2]),
+                per_rank_frames=[float(x[0]) for x in every], per_rank_seconds=[float(x[2]) for x in every],
+                world_size=world, backend=dist.get_backend())
+
+
 # ----------------------------------------------------------------------------- distributed driver
 
 def shard(items: Sequence, costs: Sequence[float], rank: int, world: int, mode: str = "lpt") -> List:
@@ -106,15 +141,9 @@ def run_sharded(work: Sequence[Tuple[str, int, int]], process_one, rank: int, wo
     done = [w[0] for w in mine]
     if dist is not None:
         dist.barrier()
-        tot = torch.tensor([float(frames), elapsed], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            tot = tot.cuda()
-        f = tot.clone()
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        m = tot.clone()
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        frames, elapsed = float(f[0]), float(m[1])
-    return dict(frames=frames, seconds=elapsed, utts=done)
+    red = reduce_job_totals(dist, frames, sum(w[2] - w[1] for w in mine), elapsed,
+                            "cuda" if dist is not None and dist.get_backend() == "nccl" else "cpu")
+    return dict(red, utts=done)
 
 
 def main(argv=None):

@@ -248,7 +248,8 @@ typedef struct f5e_dit_plan {
   float* pred;                           /* [S*N][mel] f32 */
   /* optional instrumentation (eager launches only, never inside graph capture) */
   void* timer;                           /* from f5e_timer_create, or NULL */
-  int timer_op;                          /* F5E_OP_* op class to bracket with HIP events */
+  int timer_op;                          /* F5E_OP_* op class to bracket with HIP events; a NEGATIVE value -(mask) selects
+                                            every class whose bit (1 << F5E_OP_x) is set in mask */
   /* fused AdaLN (f5e_ln_fuse): 2 L + 1 LayerNorm launches become one f5e_adaln_pre.  Needs no long skip / qk_norm. */
   int fuse_ln;                           /* 0 = separate LayerNorm launches */
   float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
@@ -280,6 +281,7 @@ int f5e_timer_create(int capacity, void** timer_out);
 int f5e_timer_destroy(void* timer);
 int f5e_timer_reset(void* timer);
 int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
+int f5e_timer_read_ops(void* timer, int* ops_out_host, int max_out, int* count_out_host); /* op class of each pair */
 
 #ifdef F5E_TOOLS
 /* Diagnostics, TOOLS build only (make -C f5e-tts_amd/csrc tools-lib -> libf5e_hip_tools.so; tools/convpos_time.py): while

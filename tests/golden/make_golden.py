@@ -474,6 +474,50 @@ def make_vq_case(modules_mod):
     print("wrote", path)
 
 
+def make_stft_case(ref_root):
+    """Pins for the transform part of a14 (log-mel front-end) and a17 (Vocos iSTFT head) from REFERENCE-HELD code:
+    the reference restates both as convolutions for its ONNX export -- ``runtime/triton_trtllm/scripts/conv_stft.py``
+    (``STFT.transform`` :156-191, ``STFT.inverse`` :193-234) and ``export_vocoder_to_onnx.py:45-59`` (``ISTFTHead``).
+    Both import only torch + scipy (+ a ``vocos`` name that is never touched on this path: an empty stand-in module
+    object is registered for the import statement, no arithmetic comes from it).  Fixture: seeded waves -> (real, imag,
+    magnitude) of the 1024 / 256 hann STFT; seeded head pre-activations z -> audio of ISTFTHead.forward."""
+    scripts = os.path.join(ref_root, "src", "f5_tts", "runtime", "triton_trtllm", "scripts")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(scripts, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    conv_stft = load("conv_stft")
+    if "vocos" not in sys.modules:
+        v = types.ModuleType("vocos")
+        v.Vocos = type("Vocos", (), {})
+        sys.modules["vocos"] = v
+    export = load("export_vocoder_to_onnx")
+    g = torch.Generator().manual_seed(1414)
+    out = {}
+    stft = conv_stft.STFT(win_len=1024, win_hop=256, fft_len=1024)
+    for tag, nw in (("a", 256 * 11 + 128), ("b", 256 * 40 + 7)):
+        wav = 0.1 * torch.randn(2, nw, generator=g)
+        wav = F.avg_pool1d(wav[:, None], 5, stride=1, padding=2)[:, 0]
+        real, imag = stft.transform(wav, return_type="realimag")
+        mag, _ = stft.transform(wav, return_type="magphase")
+        out.update({f"fwd_{tag}/wav": wav, f"fwd_{tag}/real": real, f"fwd_{tag}/imag": imag, f"fwd_{tag}/mag": mag})
+    for tag, b, t in (("a", 1, 9), ("b", 2, 33)):
+        head = export.ISTFTHead(1024, 256)
+        head.out = nn.Identity()     # the head's Linear is F.linear (pinned with every other linear); what is pinned here is
+        with torch.no_grad():        # exp / clip / cos / sin + the inverse transform on 513 log-magnitudes | 513 phases
+            z = torch.cat((1.5 * torch.randn(b, t, 513, generator=g), 3.0 * torch.randn(b, t, 513, generator=g)), -1)
+            z[:, 0, :7] = 6.0        # exp(6) > 100: exercises the clip
+            audio = head(z)
+        out.update({f"inv_{tag}/z": z, f"inv_{tag}/audio": audio})
+    path = os.path.join(HERE, "stft_head.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path, {k: tuple(v.shape) for k, v in out.items() if k.endswith(("mag", "audio"))})
+
+
 def make_layouts(dit_mod):
     """state_dict key -> shape of the full-size models as the REFERENCE constructs them (no weights: names and shapes
     are what `load_checkpoint(strict=True)` needs): F5TTS_v1_Base, and BASELINE config 5 (Small + PPG + codebook)."""
@@ -510,6 +554,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "unett":
         make_unett_case()
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "stft":
+        make_stft_case(ref)
+        return
     small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
                  conv_layers=2)
     make_dit_case(dit_mod, cfm_mod, "b1", small, b=1, n=48, nc=17, nt=9, steps=4, cfg_strength=2.0, seed=100)
@@ -525,6 +572,7 @@ def main():
     make_callers_case(ref, cfm_mod)
     make_vq_case(modules_mod)
     make_unett_case()
+    make_stft_case(ref)
     make_layouts(dit_mod)
 
 

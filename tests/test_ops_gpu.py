@@ -383,6 +383,52 @@ def test_istft_head(ops, B, T):
     close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "istft")
 
 
+def _stft_fixture():
+    import os
+
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stft_head.npz"), allow_pickle=False)
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_stft_logmel_against_reference_conv_stft_fixture(ops, tag):
+    """HIP log-mel against the magnitude spectrogram produced by the REFERENCE's conv_stft.STFT.transform (fixture
+    tests/golden/stft_head.npz): log(clamp(|S| . fb, 1e-5)) with the HTK filterbank of the product code."""
+    from f5e_tts_amd.engine import mel_filterbank
+    gfx = _stft_fixture()
+    wav, mag = gfx[f"fwd_{tag}/wav"], gfx[f"fwd_{tag}/mag"]
+    B, T = wav.shape[0], mag.shape[2]
+    fb = mel_filterbank(513, 100, 24000)
+    win, tw = fft_tables()
+    out = torch.empty(B, T, 100, device="cuda")
+    ops.stft_logmel(dev(wav), dev(win), dev(tw), dev(fb), out, 1024, 256)
+    want = torch.matmul(mag.transpose(1, 2), fb).clamp(min=1e-5).log()
+    close(out, want, 1e-3, 1e-3, "log-mel vs reference STFT magnitude")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_istft_head_against_reference_istft_head_fixture(ops, tag):
+    """HIP iSTFT head against audio produced by the REFERENCE's ISTFTHead (export_vocoder_to_onnx.py:45-59) on the same
+    pre-activations; the common hop * (T - 1) samples of batch item 0 (the reference's conv inverse leaves later batch
+    items un-normalised, see tests/test_oracle_golden.py), and item 1 after multiplying by the window envelope."""
+    gfx = _stft_fixture()
+    z, ref = gfx[f"inv_{tag}/z"], gfx[f"inv_{tag}/audio"]
+    B, T = z.shape[0], z.shape[1]
+    win, tw = fft_tables()
+    out = torch.empty(B, 256 * (T - 1), device="cuda")
+    ops.istft_head(dev(z.reshape(B * T, 1026).contiguous()), dev(win), dev(tw), torch.empty(B * T, 1024, device="cuda"),
+                   out, B, T, 1024, 256)
+    common = ref[:, : 256 * (T - 1)]
+    assert float((out[0].cpu() - common[0]).abs().max()) < 2e-4 * float(common[0].abs().max())
+    if B > 1:
+        env = torch.zeros(256 * T + 1024)
+        for f in range(T):
+            env[f * 256: f * 256 + 1024] += win ** 2
+        env = env[512: 512 + 256 * (T - 1)]
+        assert float((out[1].cpu() * env - common[1]).abs().max()) < 2e-4 * float(common[1].abs().max())
+
+
 @pytest.mark.parametrize("hint", [0, 9])
 def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     """qk_norm = 'rms_norm' (reference modules.py:464-467): RMSNorm over the 64-d head before RoPE, q and k only."""

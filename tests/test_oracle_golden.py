@@ -141,3 +141,63 @@ def test_unett_forward_matches_reference(tag, skip):
     for drop in (False, True):
         out = O.unett_forward(sd, 2, g["x"], g["cond"], g["text"], g["time"], drop, drop, g.get("mask"), skip)
         torch.testing.assert_close(out, g[f"pred_drop{int(drop)}"], **TOL)
+
+
+# ---- transform part of the mel front-end (a14) and of the Vocos iSTFT head (a17), pinned by reference-held code:
+# runtime/triton_trtllm/scripts/conv_stft.py (STFT.transform / .inverse) and export_vocoder_to_onnx.py (ISTFTHead)
+
+def _stft_fixture():
+    z = np.load(os.path.join(GOLD, "stft_head.npz"), allow_pickle=False)
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_stft_matches_reference_conv_stft(tag):
+    """The oracle's front-end STFT (torch.stft: periodic hann 1024, hop 256, centred, reflect padding) against the
+    reference's convolutional STFT: same frame count (1 + nw // 256), real / imaginary parts and magnitude.  The conv
+    form multiplies by an explicit 1024 x 1026 DFT matrix in fp32, so agreement is to fp32 summation error of a 1024-term
+    dot product (1e-4 of the largest magnitude), not bit level."""
+    g = _stft_fixture()
+    wav = g[f"fwd_{tag}/wav"]
+    window = torch.hann_window(1024, periodic=True)
+    spec = torch.stft(wav, 1024, hop_length=256, win_length=1024, window=window, center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True)
+    assert spec.shape == g[f"fwd_{tag}/real"].shape == (2, 513, 1 + wav.shape[1] // 256)
+    scale = float(g[f"fwd_{tag}/mag"].max())
+    for got, key in ((spec.real, "real"), (spec.imag, "imag"), (spec.abs(), "mag")):
+        assert float((got - g[f"fwd_{tag}/{key}"]).abs().max()) < 1e-4 * scale, key
+    # and the oracle's log-mel is exactly log(clamp(fb^T |S|, 1e-5)) of that magnitude (HTK filterbank values: the one
+    # part of a14 that stays unpinned -- they come from torchaudio, absent here and from the reference tree)
+    mel = O.log_mel_spectrogram(wav)
+    fb = O.mel_filterbank_htk(513, 100, 24000)
+    want = torch.matmul(g[f"fwd_{tag}/mag"].transpose(-1, -2), fb).transpose(-1, -2).clamp(min=1e-5).log()
+    torch.testing.assert_close(mel, want, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_istft_head_matches_reference_istft_head(tag):
+    """O.istft_head (exp, clip at 100, cos / sin, torch.istft centred) against the reference's ISTFTHead.  The reference's
+    conv form keeps hop * T samples (conv_stft.py:225-231), torch.istft -- which is what vocoder.decode runs at
+    infer/utils_infer.py:489 -- keeps hop * (T - 1): the common hop * (T - 1) samples are compared.  fp32 both sides; the
+    reference inverts through a pseudo-inverse of the DFT matrix, so 2e-4 of the peak."""
+    g = _stft_fixture()
+    z = g[f"inv_{tag}/z"]
+    vs = {"head.out.weight": torch.eye(1026), "head.out.bias": torch.zeros(1026)}
+    audio = O.istft_head(vs, z)
+    ref = g[f"inv_{tag}/audio"]
+    T = z.shape[1]
+    assert audio.shape == (z.shape[0], 256 * (T - 1)) and ref.shape == (z.shape[0], 256 * T)
+    common = ref[:, : 256 * (T - 1)]
+    assert float((audio[0] - common[0]).abs().max()) < 2e-4 * float(common[0].abs().max())
+    # Batch items > 0: the reference's conv inverse divides by the window envelope through `th.where(coff > 1e-8)` on a
+    # [1, 1, L] tensor (conv_stft.py:230-233), which addresses batch item 0 only -- later items come out UN-normalised.
+    # That is a quirk of the ONNX-export restatement, not of vocoder.decode (torch.istft normalises every item), so the
+    # oracle is held to it as "oracle x envelope == reference" there: the transform itself is pinned for those items too.
+    if z.shape[0] > 1:
+        w2 = torch.hann_window(1024, periodic=True) ** 2
+        env = torch.zeros(256 * T + 1024)
+        for f in range(T):
+            env[f * 256: f * 256 + 1024] += w2
+        env = env[512: 512 + 256 * (T - 1)]
+        for b in range(1, z.shape[0]):
+            assert float((audio[b] * env - common[b]).abs().max()) < 2e-4 * float(common[b].abs().max())
