@@ -318,6 +318,42 @@ def test_sharded_driver_world2_gloo(tmp_path):
     assert r[0]["seconds"] == r[1]["seconds"] > 0                      # MAX all-reduce
 
 
+def _bench_c4_worker(rank, world, port, out_dir):
+    """bench.py --workload C4 minus the GPU: the same work list, LPT partition and job reductions, `one_pass` stubbed."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from f5e_tts_amd.eval.eval_infer_batch import c4_work_list, flop_fwd, lpt_partition, reduce_job_totals
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    steps, warmup = 5, 2
+    utts = c4_work_list(os.path.join(GOLD, "c4_durations.csv"), world * (steps + warmup))
+    mine = [utts[i] for i in lpt_partition([flop_fwd(t) for _, t in utts], world)[rank]]
+    timed = mine[warmup:][:steps]
+    frames, gen = sum(t for _, t in timed), sum(t - r for r, t in timed)
+    red = reduce_job_totals(dist, frames, gen, 0.25 + 0.5 * rank, "cpu")      # stub wall time: rank 1 is the slow one
+    with open(os.path.join(out_dir, f"b{rank}.json"), "w") as f:
+        json.dump(dict(red, mine=mine, my_frames=frames, my_gen=gen), f)
+    dist.destroy_process_group()
+
+
+def test_bench_c4_partition_and_reductions_world2_gloo(tmp_path):
+    """The N > 1 leg of bench.py (C4 stream): every utterance lands on exactly one rank, frame counts are SUM-reduced, the
+    wall time MAX-reduced, and the line can show that `world` ranks took part (per-rank records, backend name)."""
+    import torch.multiprocessing as mp
+    from f5e_tts_amd.eval.eval_infer_batch import c4_work_list
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_bench_c4_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [json.load(open(tmp_path / f"b{i}.json")) for i in range(2)]
+    utts = c4_work_list(os.path.join(GOLD, "c4_durations.csv"), 14)
+    assert sorted(map(tuple, r[0]["mine"] + r[1]["mine"])) == sorted(utts) and len(r[0]["mine"]) == len(r[1]["mine"]) == 7
+    for x in r:
+        assert x["world_size"] == 2 and x["backend"] == "gloo"
+        assert x["frames"] == r[0]["my_frames"] + r[1]["my_frames"] and x["gen_frames"] == r[0]["my_gen"] + r[1]["my_gen"]
+        assert x["seconds"] == 0.75 and x["per_rank_seconds"] == [0.25, 0.75]
+        assert x["per_rank_frames"] == [r[0]["my_frames"], r[1]["my_frames"]]
+    assert all(600 < t <= 2048 and 0 < rr < t for rr, t in utts)
+
+
 def test_full_size_layouts_match_reference_including_codebook():
     """F5TTS_v1_Base and BASELINE config 5 (Small + PPG + Gumbel codebook) built from this package's yaml files have
     exactly the reference's state_dict names and shapes (tests/golden/layouts.json, written by the reference)."""
