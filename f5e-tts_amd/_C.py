@@ -46,6 +46,10 @@ SIGNATURES = {
     "f5e_vq_eval": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_kaldi_fbank": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F],
+    "f5e_glu": [_P, _P, _I, _P, _I, _LL, _I],
+    "f5e_dwconv": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_softmax_rows": [_P, _P, _I, _P, _I, _P, _LL, _I, _I, _F],
     "f5e_dit_forward": [_P, _P],
     "f5e_workspace_bytes": [_P, _P],
     "f5e_timer_create": [_I, C.POINTER(C.c_void_p)],

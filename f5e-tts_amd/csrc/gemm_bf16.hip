@@ -489,9 +489,10 @@ template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int sel = tile_hint % 10, ns = tile_hint / 10;
-  if (a.ln_stats || a.stats_out) {  // fused AdaLN: 64x64 tiles, ring depth by the same rule as below
+  if (a.ln_stats || a.stats_out) {  // fused AdaLN: 64x64 tiles (small M) or the 256x256 ping-pong kernel (large M)
     F5E_REQUIRE(!(a.ln_stats && a.stats_out), "gemm_bf16: a launch is an AdaLN consumer or a producer, not both");
     F5E_REQUIRE(!(EPI == EPI_QKV_ROPE && a.qn_w), "gemm_bf16: fused AdaLN and qk_norm need different tiles");
+    if (sel == 9 || (tile_hint == 0 && a.K >= 128 && (a.M + 255) / 256 >= 44)) return launch_pp(EPI, a, st, 0);
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);

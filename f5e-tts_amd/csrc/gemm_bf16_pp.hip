@@ -49,7 +49,10 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int DBG>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
+// FUSE: fused AdaLN at large M (same contract as gemm_bf16.hip, f5e_ln_fuse): 1 = consumer (A = xs, epilogue applies
+// rstd (acc - mean c[n]) + d[n] from the per-row tile statistics), 2 = producer (gate+residual epilogue also writes
+// xs = bf16(x_new (1 + next_scale)) and (mean, M2) of x_new per row and 64-column tile).
+template <int EPI, int DBG, int FUSE>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
 __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -195,6 +198,53 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   // complete here: the balancing barrier above is the last barrier instance of both groups.
   char* reg = smem + wave * 16384;
   const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
+  if constexpr (FUSE == 1) {
+    // Row statistics of this wave's 128 rows: lane l combines the `ln_parts` (mean, M2) tile partials of rows l and l + 64
+    // (Chan's formula, fixed order: identical to the 64 x 64 kernel), parks (mean, rstd) in the first KiB of the wave's
+    // LDS region; then the accumulators are normalised in place, so every epilogue below runs unchanged with bias = NULL
+    // (d carries it).
+    const int pp4 = a.ln_parts >> 2;   // f32x4 loads per row: (mean, M2) x 2 each
+    float* mr = (float*)reg;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = h * 64 + lane;
+      const float* sp = a.ln_stats + (size_t)min(mbase + r, a.M - 1) * a.ln_parts * 2;
+      f32x4 pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pq[u] = *(const f32x4*)(sp + 4 * min(u, 2 * pp4 - 1));
+      float sm = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < 2 * pp4) sm += pq[u][0] + pq[u][2];
+      const float mean = sm / (float)a.ln_parts;
+      const float cols = (float)(a.K / a.ln_parts);
+      float m2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < 2 * pp4) {
+          const float d0 = pq[u][0] - mean, d1 = pq[u][2] - mean;
+          m2 += (pq[u][1] + cols * d0 * d0) + (pq[u][3] + cols * d1 * d1);
+        }
+      *(f32x2*)(mr + r * 2) = f32x2{mean, rsqrtf(m2 / (float)a.K + a.ln_eps)};
+    }
+    const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+    f32x4 cq[4], dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = min(nbase + i * 16 + fq * 4, a.N - 4);
+      cq[i] = *(const f32x4*)(a.ln_c + eoff + n);
+      dq[i] = *(const f32x4*)(a.ln_d + eoff + n);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region, own writes
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x2 st = *(const f32x2*)(mr + (j * 16 + fr) * 2);
+      const float nm = -st[0] * st[1];                    // -mean rstd
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = st[1] * acc[i][j] + (nm * cq[i] + dq[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the statistics are read before the region is reused below
+  }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
     if (a.N % 8 == 0 && a.ldo % 8 == 0) {
       f32x4 bq[4];
@@ -237,6 +287,8 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
         bq[i] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       const int c = lane & 15;
+      f32x4 nsq = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FUSE == 2) nsq = *(const f32x4*)(a.next_scale + eoff + min(nbase + c * 4, a.N - 4)) + 1.0f;  // gate_rows == 1
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         // 64 rows x 256 B: 16 chunks of 16 B (4 fp32) per row, chunk index XORed with r & 15
@@ -276,8 +328,30 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
           for (int u = 0; u < 8; ++u) {
             const int r = (b8 * 8 + u) * 4 + (lane >> 4);
             const f32x4 v = *(const f32x4*)(reg + r * 256 + ((c ^ (r & 15)) << 4));
-            if (inb[u] && ps[u] < len[u])
-              *(f32x4*)(a.resid + (size_t)(mb + r) * a.ldr + nbase + c * 4) = xv[u] + gv[u] * v;
+            f32x4 xn = xv[u];
+            if (inb[u] && ps[u] < len[u]) {
+              xn = xv[u] + gv[u] * v;
+              *(f32x4*)(a.resid + (size_t)(mb + r) * a.ldr + nbase + c * 4) = xn;
+            }
+            if constexpr (FUSE == 2) {
+              // what the NEXT AdaLN needs from x_new (masked rows: the unchanged x): xs for its linear and (mean, M2) over
+              // this wave's 64 columns; the 16 lanes of a row are one DPP row
+              float sm = (xn[0] + xn[1]) + (xn[2] + xn[3]);
+              sm = add_xor2(add_xor1(sm));
+              sm += dpp_f32<0x124>(sm);
+              sm += dpp_f32<0x128>(sm);
+              const float mw = sm * (1.0f / 64.0f);
+              const f32x4 dv = xn - mw;
+              float q2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+              q2 = add_xor2(add_xor1(q2));
+              q2 += dpp_f32<0x124>(q2);
+              q2 += dpp_f32<0x128>(q2);
+              if (inb[u]) {
+                const f32x4 y = xn * nsq;
+                *(bf16x4*)(a.xs_out + (size_t)(mb + r) * a.ld_xs + nbase + c * 4) = f2bf4(y[0], y[1], y[2], y[3]);
+                if (c == 0) *(f32x2*)(a.stats_out + ((size_t)(mb + r) * (a.N >> 6) + (nbase >> 6)) * 2) = f32x2{mw, q2};
+              }
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the region
@@ -347,9 +421,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     }
   }
   if constexpr (EPI == EPI_QKV_ROPE) {
-    // q / k waves (one head each): the destination offset in the fragment-major layout and the cos/sin offset both split
-    // into a row part (sequence, position) and a column part (d), so a quad costs one add per address instead of the
-    // divisions and 64-bit chains of the generic epilogue (32 quads per lane with nothing to hide behind).
+    // q / k waves (one head each): bias, optional qk RMSNorm and RoPE in registers, then out through LDS (below).
     const int inner = a.heads * 64;
     if (nbase < 2 * inner) {
       const int which = nbase >= inner ? 1 : 0;
@@ -358,25 +430,28 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
       const bool rope_on = head < a.rope_heads;
       const float* qk_w = a.qn_w ? (which == 0 ? a.qn_w : a.kn_w) : nullptr;
       f32x4 bq[4], wq[4];
-      int coloff[4], csoff[4];
+      int csoff[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int d = i * 16 + fq * 4;
         bq[i] = a.bias ? *(const f32x4*)(a.bias + nbase + d) : f32x4{0.f, 0.f, 0.f, 0.f};
         wq[i] = qk_w ? *(const f32x4*)(qk_w + d) : f32x4{1.f, 1.f, 1.f, 1.f};
-        coloff[i] = i * 512 + (fq >> 1) * 8 + (fq & 1) * 4;
         csoff[i] = d;  // (d >> 1) * 2 floats
       }
       const int seq0 = mbase / a.rows_per_seq, pos0 = mbase - seq0 * a.rows_per_seq;
       const size_t seq_stride = (size_t)a.heads * a.n_pad * 64;
+      // The fragment-major image of one (position, 16-d block) is 32 contiguous bytes and consecutive positions of a
+      // 32-position tile follow each other, but the accumulator layout hands a lane 8 bytes of 16 different rows: 61 M
+      // 8-byte stores per launch at C3, each instruction touching 16 partial lines.  So the wave's RoPE'd 128 x 64
+      // sub-tile is parked in its 16 KiB share of the idle ring as [ks = d / 16][row][32 B] and leaves as 16-byte pieces,
+      // 32 consecutive rows (1 KiB, contiguous inside a position tile) per store instruction.  The four 8-byte slots of a
+      // row chunk are XORed with (row >> 2) & 3 so the 16 lanes of a ds_write_b64 group hit 16 different bank pairs.
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = j * 16 + fr;
-        if (mbase + r >= a.M) continue;
-        int seq = seq0, pos = pos0 + r;
-        while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
-        bf16* rowp = base + seq * seq_stride + (size_t)(pos >> 5) * 2048 + (pos & 31) * 16;
-        const float* csrow = a.cos_sin + (size_t)pos * 64;
+        int pos = pos0 + r;
+        while (pos >= a.rows_per_seq) pos -= a.rows_per_seq;
+        const float* csrow = a.cos_sin + (size_t)min(pos, a.rows_per_seq - 1) * 64;
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[i][j] + bq[i];
@@ -389,6 +464,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = v[i] * rn * wq[i];
         }
+        const int xr = (r >> 2) & 3;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 o = v[i];
@@ -399,8 +475,21 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
             o[2] = v[i][2] * cs[2] - v[i][3] * cs[3];
             o[3] = v[i][3] * cs[2] + v[i][2] * cs[3];
           }
-          *(bf16x4*)(rowp + coloff[i]) = f2bf4(o[0], o[1], o[2], o[3]);
+          *(bf16x4*)(reg + i * 4096 + r * 32 + ((fq ^ xr) << 3)) = f2bf4(o[0], o[1], o[2], o[3]);
         }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own region, own writes: no workgroup barrier needed
+      const int hh = lane & 1, rl = lane >> 1;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int ks = it >> 2, r = (it & 3) * 32 + rl;
+        const int xr = (r >> 2) & 3;
+        uint4 piece = *(const uint4*)(reg + ks * 4096 + r * 32 + ((hh ^ (xr >> 1)) << 4));
+        if (xr & 1) piece = make_uint4(piece.z, piece.w, piece.x, piece.y);  // the two 8-byte slots of the piece were swapped
+        int seq = seq0, pos = pos0 + r;
+        while (pos >= a.rows_per_seq) { pos -= a.rows_per_seq; ++seq; }
+        if (mbase + r < a.M)
+          *(uint4*)(base + seq * seq_stride + (size_t)(pos >> 5) * 2048 + ks * 512 + (pos & 31) * 16 + hh * 8) = piece;
       }
       return;
     }
@@ -416,7 +505,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 // burst, each waiting for the whole burst to drain (the stores cost 63 of 310 us at C3's FF1, the HBM being idle the
 // rest of the time).  Workgroups that own one tile fewer than the busiest ones (n_tiles % gridDim.x != 0) have a tile time of
 // slack: they start late by an even share of it, which takes the CUs out of phase at no cost in makespan.
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
@@ -432,20 +521,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   for (int p = blockIdx.x; p < n_tiles; p += grid) {
-    pp_tile<EPI, DBG>(a, smem, p, n_tiles);
+    pp_tile<EPI, DBG, FUSE>(a, smem, p, n_tiles);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
     __builtin_amdgcn_s_barrier();
   }
 }
 
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, int FUSE = 0>
 int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
   a.m_major = a.M > a.N;
   constexpr int lds = 8 * HALF_BYTES;
   static F5eDeviceOnce lds_once;  // 128 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG>), lds);
+  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG, FUSE>), lds);
   int n_cu = f5e_cu_count() / 8 * 8;
   if (n_cu == 0) n_cu = 8;
   const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
@@ -453,7 +542,7 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   const int n_tiles = a.tiles_m * a.tiles_n;
   const char* pe = getenv("F5E_PP_PERSIST");  // read every launch: A/B switch for tuning runs
   const int grid = (pe && pe[0] == '0') ? n_tiles : (n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu);
-  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG, FUSE>), dim3(grid), dim3(512), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_pp");
   return F5E_OK;
 }
@@ -470,6 +559,21 @@ int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
   if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
   if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
   if (dbg == 6) return launch_pp_t<EPI_BF16_GELU, 6>(a, st);
+  if (a.ln_stats) {   // fused-AdaLN consumer (checked by the dispatcher: parts a multiple of 4 up to 16, one table row)
+    switch (epi) {
+      case EPI_BF16: return launch_pp_t<EPI_BF16, 0, 1>(a, st);
+      case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU, 0, 1>(a, st);
+      case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 0, 1>(a, st);
+      case EPI_F32: return launch_pp_t<EPI_F32, 0, 1>(a, st);
+    }
+    f5e_set_error("gemm_bf16_pp: epilogue %d cannot consume AdaLN statistics", epi);
+    return F5E_ERR_BAD_SHAPE;
+  }
+  if (a.stats_out) {  // producer: gate + residual only, full 64-column strips, one gate row
+    F5E_REQUIRE(epi == EPI_GATE_RES && a.N % 64 == 0 && a.gate_rows == 1 && a.N % 4 == 0,
+                "gemm_bf16_pp: the AdaLN producer is the gate+residual epilogue with N %% 64 == 0 and one gate row");
+    return launch_pp_t<EPI_GATE_RES, 0, 2>(a, st);
+  }
   switch (epi) {
     case EPI_BF16: return launch_pp_t<EPI_BF16>(a, st);
     case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU>(a, st);

@@ -139,6 +139,7 @@ class DiTEngine:
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
         # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
         self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
+        self.fuse_ln_pp = os.environ.get("F5E_FUSE_LN_PP", "1") != "0"   # the large-M (ping-pong GEMM) form of the same
         self._loops = threading.local()   # per-thread LRU of persistent loop states (see _LoopState)
         self._tables: Dict[tuple, Tensor] = {}
         self._lock = threading.Lock()
@@ -174,7 +175,13 @@ class DiTEngine:
 
     # Above this many rows per launch the 128x128 GEMM tiles win (QKV / FF1 at M = 3752: 41 / 23 us against 54 / 31 us for
     # the 64x64 tile the fusion needs, i.e. more than the two LayerNorm launches it saves): keep LayerNorm separate there.
+    # From 44 row tiles of 256 on (gemm_bf16.hip's crossover) the GEMMs run the 256x256 ping-pong kernel, which carries the
+    # fusion again: at C3 each LayerNorm launch is 369 MB of HBM traffic (60 us at the roofline), the fused form 123 MB.
     LN_FUSE_MAX_ROWS = 2800
+    LN_FUSE_PP_MIN_ROWS = 43 * 256 + 1
+
+    def fuse_rows_ok(self, M: int) -> bool:
+        return M <= self.LN_FUSE_MAX_ROWS or (M >= self.LN_FUSE_PP_MIN_ROWS and self.fuse_ln_pp)
 
     @property
     def can_fuse_ln(self) -> bool:
@@ -369,7 +376,7 @@ class DiTEngine:
                   cd: Optional[Tensor] = None) -> "_Plan":
         cfg = self.cfg
         M = S * N
-        fuse = bool(cd is not None and self.can_fuse_ln and M <= self.LN_FUSE_MAX_ROWS and cd.shape[1] == 1)
+        fuse = bool(cd is not None and self.can_fuse_ln and self.fuse_rows_ok(M) and cd.shape[1] == 1)
         p = self.plan_shape(S, B, N, mod.shape[1], fuse)
         w, arena = self.workspace(p)
         assert int(w.n_pad) == p.n_pad

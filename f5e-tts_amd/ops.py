@@ -364,6 +364,44 @@ def istft_head(z: Tensor, window: Tensor, twiddle: Tensor, frames_ws: Tensor, ou
     return out
 
 
+def kaldi_fbank(wav: Tensor, window: Tensor, twiddle: Tensor, fb: Tensor, out: Tensor, win: int, shift: int,
+                in_scale: float = 32768.0, preemph: float = 0.97, eps: float = 1.1920928955078125e-07):
+    require_device()
+    B, nw = wav.shape
+    check(lib().f5e_kaldi_fbank(_stream(), _p(wav, F32, "wav"), nw, wav.stride(0), _p(window, F32, "window"),
+                                _p(twiddle, F32, "twiddle"), _p(fb, F32, "fb"), _p(out, F32, "out"), B, win, shift,
+                                fb.shape[1], in_scale, preemph, eps), "f5e_kaldi_fbank")
+    return out
+
+
+def glu(x: Tensor, out: Tensor):
+    """out[r, c] = x[r, c] * sigmoid(x[r, C + c]); x f32 [rows, 2C], out f32 [rows, C] (row strides free)."""
+    require_device()
+    rows, C = out.shape
+    check(lib().f5e_glu(_stream(), _p(x, F32, "x"), x.stride(0), _p(out, F32, "out"),
+                        out.stride(0), rows, C), "f5e_glu")
+    return out
+
+
+def dwconv(x: Tensor, w_t: Tensor, bias: Tensor, out: Tensor, keep: Optional[Tensor] = None):
+    """Depthwise conv over time, channels-last f32 [B, T, C]; w_t [K, C]."""
+    require_device()
+    B, T, Cc = x.shape
+    check(lib().f5e_dwconv(_stream(), _p(x, F32, "x"), _p(w_t, F32, "w_t"), _p(bias, F32, "bias"), _p(keep, F32, "keep"),
+                           _p(out, F32, "out"), B, T, Cc, w_t.shape[0]), "f5e_dwconv")
+    return out
+
+
+def softmax_rows(x: Tensor, out: Tensor, L: int, scale: float, kv_len: Optional[Tensor] = None, rows_per_seq: int = 1):
+    """Row softmax of scale * x[:, :len] (zeros beyond); x, out f32 [rows, >= L]."""
+    require_device()
+    rows = x.shape[0]
+    check(lib().f5e_softmax_rows(_stream(), _p(x, F32, "x"), x.stride(0), _p(out, F32, "out"), out.stride(0),
+                                 _p(kv_len, I32, "kv_len"), rows, rows_per_seq if kv_len is not None else max(rows, 1), L,
+                                 scale), "f5e_softmax_rows")
+    return out
+
+
 def dit_forward(plan: "_C.DitPlan"):
     require_device()
     check(lib().f5e_dit_forward(_stream(), C.byref(plan)), "f5e_dit_forward")

@@ -210,6 +210,26 @@ int f5e_stft_logmel(f5e_stream st, const float* wav, int nw, int ldw, const floa
 int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, const float* twiddle, float* frames_ws,
                    float* out, int B, int T, int n_fft, int hop);
 
+/* ---------------------------------------------------------------- PPG extractor front ------------ */
+
+/* torchaudio.compliance.kaldi.fbank as the reference calls it (ppg/wenet/dataset/feats.py:66-72): frame f = samples
+ * [f shift, f shift + win) of wav * in_scale (snip_edges), minus its mean, pre-emphasised (x[j] - preemph x[j-1], x[-1] = x[0]),
+ * times window[win] (povey), zero-padded to 512, |rfft|^2 . fb[257][n_mels], log(max(., eps)).
+ * out f32 [B][T][n_mels], T = 1 + (nw - win) / shift.  twiddle f32 [256][2] = (cos, -sin)(2 pi k / 512). */
+int f5e_kaldi_fbank(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+                    const float* fb, float* out, int B, int win, int shift, int n_mels, float in_scale, float preemph,
+                    float eps);
+/* y[r][c] = x[r][c] * sigmoid(x[r][C + c])   (F.glu over channels, ppg/wenet/transformer/convolution.py:119) */
+int f5e_glu(f5e_stream st, const float* x, int ldx, float* y, int ldy, long long rows, int C);
+/* Depthwise Conv1d(C, C, K, padding (K-1)/2, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [K][C];
+ * keep (optional f32 [B][T], 0/1): frames with keep == 0 count as zeros (convolution.py:100-101).  Odd K <= 31. */
+int f5e_dwconv(f5e_stream st, const float* x, const float* w_t, const float* bias, const float* keep, float* y, int B,
+               int T, int C, int K);
+/* y[r][k] = softmax_k(scale * x[r][k], k < len) for k < len, 0 for len <= k < ldy; len = kv_len[r / rows_per_seq] or L
+ * (ppg/wenet/transformer/attention.py:75-87). */
+int f5e_softmax_rows(f5e_stream st, const float* x, int ldx, float* y, int ldy, const int* kv_len, long long rows,
+                     int rows_per_seq, int L, float scale);
+
 /* ---------------------------------------------------------------- fused DiT evaluation ----------------------- */
 
 typedef struct f5e_dit_block_weights {

@@ -518,6 +518,65 @@ def make_stft_case(ref_root):
     print("wrote", path, {k: tuple(v.shape) for k, v in out.items() if k.endswith(("mag", "audio"))})
 
 
+def make_ppg_case(ref_root):
+    """Pins for SURVEY row f3 from the reference's own PPG classes: ``ppg/asr_model.py`` (``init_asr_model`` ->
+    ``ASRModel.extract``: wenet ConformerEncoder + the 256-d ``linear`` head + ``ce.fc`` logits, with ``GlobalCMVN``) and
+    ``ppg/ppg_model.py`` (``PPGModelWapper.mel_to_ppg`` / ``ppg_to_target``).  A reduced encoder (64-d, 4 heads, 2 blocks,
+    same module classes / code paths as the 256-d default) keeps the fixture small; every parameter and BatchNorm buffer
+    is seeded-random.  kaldi fbank itself lives in torchaudio (absent): features here are seeded noise of fbank shape, and
+    ``torchaudio.compliance.kaldi`` is registered as an EMPTY stand-in only so that ``ppg_model.py`` imports."""
+    src = os.path.join(ref_root, "src", "f5_tts")
+    if "f5_tts" not in sys.modules or not hasattr(sys.modules["f5_tts"], "__path__"):
+        pkg = types.ModuleType("f5_tts")
+        pkg.__path__ = [src]
+        sys.modules["f5_tts"] = pkg
+    pk = types.ModuleType("f5_tts.ppg")
+    pk.__path__ = [os.path.join(src, "ppg")]
+    sys.modules["f5_tts.ppg"] = pk
+    for name in ("torchaudio", "torchaudio.transforms", "torchaudio.compliance", "torchaudio.compliance.kaldi"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchaudio"].transforms = sys.modules["torchaudio.transforms"]
+    sys.modules["torchaudio"].compliance = sys.modules["torchaudio.compliance"]
+    sys.modules["torchaudio.compliance"].kaldi = sys.modules["torchaudio.compliance.kaldi"]
+    asr = importlib.import_module("f5_tts.ppg.asr_model")
+    ppg_model = importlib.import_module("f5_tts.ppg.ppg_model")
+    cmvn_mod = importlib.import_module("f5_tts.ppg.wenet.transformer.cmvn")
+    cfg = dict(cmvn_file=None, is_json_cmvn=True, input_dim=80, output_dim=40, encoder="conformer", decoder="transformer",
+               encoder_conf=dict(output_size=64, attention_heads=4, linear_units=128, num_blocks=2),
+               decoder_conf=dict(attention_heads=4, linear_units=64, num_blocks=1),
+               model_conf=dict(ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False, sv_conf=dict(use_sv=False)))
+    torch.manual_seed(4242)
+    model = asr.init_asr_model(cfg)
+    g = torch.Generator().manual_seed(4243)
+    model.encoder.global_cmvn = cmvn_mod.GlobalCMVN(torch.randn(80, generator=g), 0.5 + torch.rand(80, generator=g))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.ndim == 1:          # LayerNorm / BatchNorm affine, biases: away from their 1 / 0 defaults
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if name.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+    model.eval()
+    feats = 4.0 * torch.randn(2, 101, 80, generator=g) + 8.0
+    lens = torch.tensor([101, 77])
+    feats[1, 77:] = 0.0                      # padded frames of a batch are zeros (pad_sequence), before CMVN
+    with torch.no_grad():
+        ppg, logits = model.extract(feats, lens, stream=False)
+        wrap = object.__new__(ppg_model.PPGModelWapper)       # __init__ loads files from absolute paths: skipped
+        wrap.ppg_model, wrap.output_type, wrap.map_mix_ratio = model, "ppg", 1.0
+        wrap.ppg_frame_length, wrap.mel_f_shift, wrap.device = 20, 10, "cpu"
+        tgt, true_len = wrap.mel_to_ppg(feats, lens)
+    keep = ("encoder.embed.", "encoder.encoders.", "encoder.after_norm.", "encoder.global_cmvn.", "linear.", "ce.fc.")
+    out = {"w/" + k: v for k, v in model.state_dict().items() if k.startswith(keep) and "concat_linear" not in k}
+    out.update({"feats": feats, "lens": lens, "ppg": ppg, "logits": logits, "target": tgt, "true_len": true_len})
+    path = os.path.join(HERE, "ppg_conformer.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path, tuple(ppg.shape), tuple(logits.shape), true_len.tolist())
+
+
 def make_layouts(dit_mod):
     """state_dict key -> shape of the full-size models as the REFERENCE constructs them (no weights: names and shapes
     are what `load_checkpoint(strict=True)` needs): F5TTS_v1_Base, and BASELINE config 5 (Small + PPG + codebook)."""
@@ -557,6 +616,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "stft":
         make_stft_case(ref)
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "ppg":
+        make_ppg_case(ref)
+        return
     small = dict(dim=128, depth=2, heads=2, dim_head=64, ff_mult=2, mel_dim=20, text_num_embeds=50, text_dim=32,
                  conv_layers=2)
     make_dit_case(dit_mod, cfm_mod, "b1", small, b=1, n=48, nc=17, nt=9, steps=4, cfg_strength=2.0, seed=100)
@@ -573,6 +635,7 @@ def main():
     make_vq_case(modules_mod)
     make_unett_case()
     make_stft_case(ref)
+    make_ppg_case(ref)
     make_layouts(dit_mod)
 
 

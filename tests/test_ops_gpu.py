@@ -455,12 +455,15 @@ def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     close(unq(vt, vi)[:, :, :N], lin[2], 2 ** -7, 4e-3, "v untouched")
 
 
-@pytest.mark.parametrize("S,N,D,NO,mean_shift,masked", [(2, 469, 1024, 3072, 0.0, False), (2, 100, 768, 1536, 0.7, True),
-                                                          (1, 33, 1024, 100, 0.3, False)])
-def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked):
+@pytest.mark.parametrize("S,N,D,NO,mean_shift,masked,hint", [
+    (2, 469, 1024, 3072, 0.0, False, 0), (2, 100, 768, 1536, 0.7, True, 0), (1, 33, 1024, 100, 0.3, False, 0),
+    # hint 9 = the 256 x 256 ping-pong kernel (what large-M launches pick by themselves): partial row tiles, two sequences
+    # inside one wave's 128 rows, masked rows, D = 768 (12 statistics tiles), a skinny consumer (N = 100)
+    (2, 469, 1024, 3072, 0.0, False, 9), (3, 150, 768, 1536, 0.7, True, 9), (1, 300, 1024, 100, 0.3, False, 9)])
+def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     """LayerNorm+modulate folded into the GEMMs either side of it (f5e_ln_fuse): adaln_pre / the gate+residual producer
     -> consumer linear, against LN(x)(1+scale)+shift -> linear in fp32 (reference modules.py:308-314 + :452-454,
-    :637 + :349) and against the unfused HIP ops."""
+    :637 + :349) and against the unfused HIP ops.  Both kernel families: 64 x 64 tiles (small M) and ping-pong (large M)."""
     M, P = S * N, D // 64
     x = torch.randn(M, D, generator=g(70)) * 1.5 + mean_shift
     mod = torch.randn(1, 3 * D, generator=g(71)) * 0.3                      # scale | shift | gate
@@ -479,7 +482,7 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked):
     close(stats[:, :, 0], x.mean(1, keepdim=True).expand(M, P), 1e-5, 1e-6, "pre mean")
     close(stats[:, :, 1].sum(1), ((x - x.mean(1, keepdim=True)) ** 2).sum(1), 1e-5, 1e-4, "pre M2")
     out = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N))
+    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N), tile_hint=hint)
     hn = torch.empty(M, D, device="cuda", dtype=BF)
     ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:2 * D], rows_per_seq=N)
     unf = torch.empty(M, NO, device="cuda")
@@ -494,14 +497,15 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked):
     a2 = (torch.randn(M, K2, generator=g(74))).to(BF)
     w2 = (torch.randn(D, K2, generator=g(75)) / math.sqrt(K2)).to(BF)
     b2 = torch.randn(D, generator=g(76)) * 0.1
-    seq_len = torch.tensor([N - 7, N][:S], dtype=torch.int32) if masked else None
+    seq_len = torch.tensor([N - 7, N, N - 20][:S], dtype=torch.int32) if masked else None
     x_plain, x_fused = xd.clone(), xd.clone()
     ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2), x_plain, modd[:, 2 * D:], N,
-                                seq_len=dev(seq_len) if masked else None)
+                                seq_len=dev(seq_len) if masked else None, tile_hint=hint)
     xs2 = torch.zeros(M, D, device="cuda", dtype=BF)
     st2 = torch.zeros(M, P, 2, device="cuda")
     ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2), x_fused, modd[:, 2 * D:], N,
-                                seq_len=dev(seq_len) if masked else None, ln=ops.ln_producer(xs2, modd[:, :D], st2))
+                                seq_len=dev(seq_len) if masked else None, ln=ops.ln_producer(xs2, modd[:, :D], st2),
+                                tile_hint=hint)
     assert torch.equal(x_plain, x_fused)                                    # the residual update itself is unchanged
     xn = x_fused.cpu()
     if masked:
@@ -511,6 +515,6 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked):
     close(st2[:, :, 0], tiles.mean(2), 1e-5, 1e-6, "producer tile mean")
     close(st2[:, :, 1], ((tiles - tiles.mean(2, keepdim=True)) ** 2).sum(2), 1e-4, 1e-4, "producer tile M2")
     out2 = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N))
+    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N), tile_hint=hint)
     ref2 = (F.layer_norm(xn, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
     assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) / float(ref2.std()) < 4e-3
