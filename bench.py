@@ -401,7 +401,7 @@ def main():
                      "HIP log-mel front-end + Vocos decode on GPU")
     if args.workload == "C4":
         workload_desc = ("C4: F5TTS_v1_Base random-init, one utterance per call, lengths from the reference's LibriSpeech-PC "
-                         f"cross-sentence list (750-1875 frames), euler NFE={NFE}, CFG={CFG}, sway={SWAY}, LPT-sharded over "
+                         f"cross-sentence list (610-1390 frames, mean 927), euler NFE={NFE}, CFG={CFG}, sway={SWAY}, LPT-sharded over "
                          f"{world} rank(s), hipGraph ODE step, HIP log-mel + Vocos on GPU")
     if args.workload == "C5":
         workload_desc = (f"C5: F5TTS_Small + PPG (dim 768, 18 blocks) random-init, batch 1, N_ref={N_REF} N={N_TOTAL} frames, "

@@ -88,6 +88,7 @@ class DitPlan(C.Structure):
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
         + [("timer", _P), ("timer_op", _I)]
         + [("fuse_ln", _I), ("ln_stats", _P), ("cd", _P), ("cd_stride", _I)]
+        + [("mall_prefetch", _I)]
     )
 
 WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp")

@@ -31,6 +31,8 @@ struct AttnArgs {
   const int* kv_len;  // [S] or null (= rows_per_seq)
   int S, H, rows_per_seq, n_pad;
   float scale_log2e;  // (1/sqrt(64)) * log2(e)
+  int n_main;         // workgroups beyond it only prefetch (NSPLIT == 4 launches: 256 threads)
+  F5ePrefetch pf;
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -43,13 +45,17 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
+  if (NSPLIT == 4 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, threadIdx.x, red);
+    return;
+  }
 
   const int qtiles = (a.rows_per_seq + 31) / 32;
   // XCD-aware order: blocks with equal blockIdx%8 share an XCD (and its L2); give each XCD a contiguous range of
   // logical ids so all q-tiles of one (sequence, head) -- which re-read the same K/V -- hit the same L2.
   int bid = blockIdx.x;
   {
-    const int nblk = gridDim.x;
+    const int nblk = a.n_main;
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, const void* v, void* o, int ldo,
-                              const int* kv_len, int S, int H, int rows_per_seq, int n_pad, int splits) {
+int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* v, void* o, int ldo, const int* kv_len,
+                      int S, int H, int rows_per_seq, int n_pad, int splits, const F5ePrefetch* pf) {
   F5E_REQUIRE(q && k && v && o, "flash_attn: null pointer");
   F5E_REQUIRE(S > 0 && H > 0 && rows_per_seq > 0, "flash_attn: empty problem");
   F5E_REQUIRE(n_pad % 64 == 0 && n_pad >= rows_per_seq, "flash_attn: n_pad=%d must be a multiple of 64 and >= %d",
@@ -407,6 +413,7 @@ extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, cons
   a.kv_len = kv_len; a.S = S; a.H = H; a.rows_per_seq = rows_per_seq; a.n_pad = n_pad;
   a.scale_log2e = 0.125f * 1.4426950408889634f;
   const int grid = ((rows_per_seq + 31) / 32) * H * S;
+  a.n_main = grid;
   // Large problems: K/V shared through LDS by 128-query workgroups (splits = -1 forces it, 0 picks it when the
   // LDS-free kernel would already have >= 8 waves per CU without any KV split)
   if (splits == -1 || (splits == 0 && grid >= 8192)) {
@@ -424,9 +431,19 @@ extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, cons
   switch (splits) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid), dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid), dim3(128), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a); break;
+    case 4: {
+      const int npf = f5e_prefetch_wgs(pf);
+      if (npf) a.pf = *pf;
+      hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(grid + npf), dim3(256), 0, st, a);
+      break;
+    }
     default: F5E_REQUIRE(false, "flash_attn: splits must be 0 (auto), -1 (LDS-shared), 1, 2 or 4");
   }
   F5E_LAUNCH_CHECK("flash_attn");
   return F5E_OK;
+}
+
+extern "C" int f5e_flash_attn(hipStream_t st, const void* q, const void* k, const void* v, void* o, int ldo,
+                              const int* kv_len, int S, int H, int rows_per_seq, int n_pad, int splits) {
+  return f5e_flash_attn_pf(st, q, k, v, o, ldo, kv_len, S, H, rows_per_seq, n_pad, splits, nullptr);
 }

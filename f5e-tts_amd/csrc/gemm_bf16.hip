@@ -71,10 +71,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs));
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
+  if (NT == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
+    return;
+  }
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
   int bid = blockIdx.x;
   {
-    const int nblk = gridDim.x;
+    const int nblk = a.n_main;
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -462,7 +466,10 @@ int launch(GemmArgs& a, hipStream_t st) {
   a.m_major = a.M > a.N;
   a.tile_magic = div_magic_of(a.m_major ? a.tiles_n : a.tiles_m);
   a.rps_magic = div_magic_of(a.rows_per_seq);
-  const int grid = a.tiles_m * a.tiles_n;
+  a.n_main = a.tiles_m * a.tiles_n;
+  // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
+  const int grid = a.n_main + ((WGM * WGN == 4 && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
+  if (grid == a.n_main) a.pf = F5ePrefetch{};
   constexpr int lds = NSTAGE * (BM + BN) * 64 * 2 + (FUSE ? 1024 : 0);
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
   if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), lds);
@@ -478,6 +485,8 @@ int launch_dbg(GemmArgs& a, hipStream_t st) {
   a.m_major = 0;
   a.tile_magic = div_magic_of(a.tiles_m);
   a.rps_magic = div_magic_of(a.rows_per_seq);
+  a.n_main = a.tiles_m * a.tiles_n;
+  a.pf = F5ePrefetch{};
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, EPI, 3, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), 3 * 128 * 128, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_dbg");
   return F5E_OK;
@@ -569,16 +578,12 @@ int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
 
 }  // namespace
 
-extern "C" {
-
-int f5e_gemm_bf16_bias(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
-                       int ldo, int M, int N, int K, int act, int out_f32, int tile_hint) {
-  return f5e_gemm_bf16_bias_ln(st, A, lda, W, ldw, bias, out, ldo, M, N, K, act, out_f32, tile_hint, nullptr);
-}
-
-int f5e_gemm_bf16_bias_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
-                          int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln) {
+// Internal entry points (f5e_dit_forward): the *_ln ABI functions plus an Infinity-Cache prefetch hint
+int f5e_gemm_bf16_bias_pf(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                          int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln,
+                          const F5ePrefetch* pf) {
   GemmArgs a{};
+  if (pf) a.pf = *pf;
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
   if (int e = check_common(a)) return e;
@@ -593,19 +598,12 @@ int f5e_gemm_bf16_bias_ln(hipStream_t st, const void* A, int lda, const void* W,
   return dispatch<EPI_BF16>(a, st, tile_hint);
 }
 
-int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
-                                float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
-                                const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
-                                int N, int K, int tile_hint) {
-  return f5e_gemm_bf16_gate_residual_ln(st, A, lda, W, ldw, bias, resid, ldr, gate, gate_stride, gate_rows, eval_ptr,
-                                        eval_stride, rows_per_seq, seq_len, M, N, K, tile_hint, nullptr);
-}
-
-int f5e_gemm_bf16_gate_residual_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+int f5e_gemm_bf16_gate_residual_pf(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
                                    float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
                                    const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
-                                   int N, int K, int tile_hint, const f5e_ln_fuse* ln) {
+                                   int N, int K, int tile_hint, const f5e_ln_fuse* ln, const F5ePrefetch* pf) {
   GemmArgs a{};
+  if (pf) a.pf = *pf;
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
   a.resid = resid; a.ldr = ldr; a.gate = gate; a.gate_stride = gate_stride; a.gate_rows = gate_rows;
@@ -621,19 +619,12 @@ int f5e_gemm_bf16_gate_residual_ln(hipStream_t st, const void* A, int lda, const
   return dispatch<EPI_GATE_RES>(a, st, tile_hint);
 }
 
-int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
-                           void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
-                           const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
-                           int tile_hint) {
-  return f5e_gemm_bf16_qkv_rope_ln(st, A, lda, W, ldw, bias, q, k, vt, n_pad, heads, rope_heads, cos_sin, q_norm_w,
-                                   k_norm_w, rows_per_seq, M, K, tile_hint, nullptr);
-}
-
-int f5e_gemm_bf16_qkv_rope_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
-                              void* q, void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
-                              const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
-                              int tile_hint, const f5e_ln_fuse* ln) {
+int f5e_gemm_bf16_qkv_rope_pf(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
+                              void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                              const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K, int tile_hint,
+                              const f5e_ln_fuse* ln, const F5ePrefetch* pf) {
   GemmArgs a{};
+  if (pf) a.pf = *pf;
   a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias;
   a.M = M; a.N = 3 * heads * 64; a.K = K;
   a.q = (bf16*)q; a.k = (bf16*)k; a.vt = (bf16*)vt; a.n_pad = n_pad; a.heads = heads; a.rope_heads = rope_heads;
@@ -647,6 +638,50 @@ int f5e_gemm_bf16_qkv_rope_ln(hipStream_t st, const void* A, int lda, const void
               "gemm_bf16_qkv_rope: n_pad=%d must be a multiple of 64 and >= rows_per_seq=%d", n_pad, rows_per_seq);
   if (int e = set_consumer(a, ln, bias)) return e;
   return dispatch<EPI_QKV_ROPE>(a, st, tile_hint);
+}
+
+extern "C" {
+
+int f5e_gemm_bf16_bias(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                       int ldo, int M, int N, int K, int act, int out_f32, int tile_hint) {
+  return f5e_gemm_bf16_bias_ln(st, A, lda, W, ldw, bias, out, ldo, M, N, K, act, out_f32, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_bias_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                          int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln) {
+  return f5e_gemm_bf16_bias_pf(st, A, lda, W, ldw, bias, out, ldo, M, N, K, act, out_f32, tile_hint, ln, nullptr);
+}
+
+int f5e_gemm_bf16_gate_residual(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                int N, int K, int tile_hint) {
+  return f5e_gemm_bf16_gate_residual_ln(st, A, lda, W, ldw, bias, resid, ldr, gate, gate_stride, gate_rows, eval_ptr,
+                                        eval_stride, rows_per_seq, seq_len, M, N, K, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_gate_residual_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                   float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
+                                   const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
+                                   int N, int K, int tile_hint, const f5e_ln_fuse* ln) {
+  return f5e_gemm_bf16_gate_residual_pf(st, A, lda, W, ldw, bias, resid, ldr, gate, gate_stride, gate_rows, eval_ptr,
+                                        eval_stride, rows_per_seq, seq_len, M, N, K, tile_hint, ln, nullptr);
+}
+
+int f5e_gemm_bf16_qkv_rope(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
+                           void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                           const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                           int tile_hint) {
+  return f5e_gemm_bf16_qkv_rope_ln(st, A, lda, W, ldw, bias, q, k, vt, n_pad, heads, rope_heads, cos_sin, q_norm_w,
+                                   k_norm_w, rows_per_seq, M, K, tile_hint, nullptr);
+}
+
+int f5e_gemm_bf16_qkv_rope_ln(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias,
+                              void* q, void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
+                              const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
+                              int tile_hint, const f5e_ln_fuse* ln) {
+  return f5e_gemm_bf16_qkv_rope_pf(st, A, lda, W, ldw, bias, q, k, vt, n_pad, heads, rope_heads, cos_sin, q_norm_w,
+                                   k_norm_w, rows_per_seq, M, K, tile_hint, ln, nullptr);
 }
 
 }  // extern "C"

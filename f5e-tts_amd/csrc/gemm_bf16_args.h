@@ -19,7 +19,7 @@ struct GemmArgs {
   unsigned tile_magic;   // floor(2^32 / (m_major ? tiles_n : tiles_m)): tile decode without a division (div_magic)
   int rows_per_seq;
   unsigned rps_magic;    // floor(2^32 / rows_per_seq)
-  int pad0_;
+  int n_main;            // tiles_m * tiles_n: workgroups beyond it only prefetch (F5ePrefetch), 64x64 .. 128x128 kernels
   // ---- epilogue operands ----
   const float* bias;
   void* out; int ldo;
@@ -43,9 +43,10 @@ struct GemmArgs {
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
   int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
+  F5ePrefetch pf;  // weights of the next kernels, pulled into the Infinity Cache by grid-tail workgroups (small M only)
 };
 
-static_assert(offsetof(GemmArgs, pad0_) + sizeof(int) == 64, "hot kernarg fields must fill exactly the first 64-byte line");
+static_assert(offsetof(GemmArgs, n_main) + sizeof(int) == 64, "hot kernarg fields must fill exactly the first 64-byte line");
 
 // floor(n / d) for 0 <= n < 2^31, d >= 1, magic = min(floor(2^32 / d), 2^32 - 1): one mul_hi + one correction step
 // (s_mul_hi_u32 on uniform operands) instead of the ~40-instruction reciprocal sequence hipcc emits for `/`.

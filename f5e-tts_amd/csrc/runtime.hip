@@ -218,22 +218,32 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos_ln(st, p->c1, D, p->convpos_w2, p->convpos_b2, p->x, D, p->h0, D, p->S, p->N, D,
                                              p->convpos_groups, p->hn, D, p->mod + D, row_stride, p->mod_rows,
                                              p->eval_ptr, eval_stride, p->ln_stats, parts));
+    // Infinity-Cache prefetch (f5e_common.h): every GEMM / attention launch of a block drags the weights of the launch after
+    // next into the memory-side cache with a few grid-tail workgroups, so the batch-1 GEMMs stop waiting for HBM.
+    const bool pfon = p->mall_prefetch != 0;
+    const unsigned b_out = (unsigned)((size_t)D * inner * 2), b_ff = (unsigned)((size_t)p->FF * D * 2);
+    const unsigned b_qkv = (unsigned)((size_t)3 * inner * D * 2);
     for (int l = 0; l < p->L; ++l) {
       const f5e_dit_block_weights& w = p->blocks[l];
       F5E_REQUIRE(!w.q_norm_w, "dit_forward: fused AdaLN and qk_norm are exclusive");
       const float* mb = p->mod + (size_t)l * 6 * D;
       const float* cdl = p->cd + (size_t)l * ls;
+      F5ePrefetch pf_qkv{{w.w_out, nullptr}, {b_out, 0}}, pf_attn{{w.w_ff1, nullptr}, {b_ff, 0}};
+      F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
+      F5ePrefetch pf_ff1{{l + 1 < p->L ? p->blocks[l + 1].w_qkv : p->w_proj, nullptr},
+                         {l + 1 < p->L ? b_qkv : (unsigned)((size_t)p->mel * D * 2), 0}};
       cons.c = cdl; cons.d = cdl + 3 * inner;
-      F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_ln(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
-                                        p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons));
-      F5E_TIMED(F5E_OP_ATTN, f5e_flash_attn(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0));
+      F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_pf(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
+                                        p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons, pfon ? &pf_qkv : nullptr));
+      F5E_TIMED(F5E_OP_ATTN, f5e_flash_attn_pf(st, p->q, p->k, p->vt, p->ao, inner, p->seq_len, p->S, p->H, p->N, p->n_pad, 0,
+                                               pfon ? &pf_attn : nullptr));
       prod.next_scale = mb + 4 * D;  // scale_mlp
-      F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual_ln(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D,
+      F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual_pf(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D,
                                           row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D,
-                                          inner, 0, &prod));
+                                          inner, 0, &prod, pfon ? &pf_out : nullptr));
       cons.c = cdl + 6 * inner; cons.d = cdl + 6 * inner + p->FF;
-      F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_ln(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
-                                    F5E_ACT_GELU_TANH, 0, 0, &cons));
+      F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_pf(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
+                                    F5E_ACT_GELU_TANH, 0, 0, &cons, pfon ? &pf_ff1 : nullptr));
       // next norm: attn_norm of block l+1 (scale_msa at +D) or the final AdaLN (scale first: modules.py:333)
       prod.next_scale = (l + 1 < p->L) ? mb + 6 * D + D : p->mod + (size_t)p->L * 6 * D;
       F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_ln(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,

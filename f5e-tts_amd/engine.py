@@ -140,6 +140,7 @@ class DiTEngine:
         # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
         self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
         self.fuse_ln_pp = os.environ.get("F5E_FUSE_LN_PP", "1") != "0"   # the large-M (ping-pong GEMM) form of the same
+        self.mall_prefetch = os.environ.get("F5E_MALL_PREFETCH", "1") != "0"  # Infinity-Cache weight prefetch at small M
         self._loops = threading.local()   # per-thread LRU of persistent loop states (see _LoopState)
         self._tables: Dict[tuple, Tensor] = {}
         self._lock = threading.Lock()
@@ -401,6 +402,8 @@ class DiTEngine:
         p.w_proj, p.b_proj = self.proj_w.data_ptr(), self.proj_b.data_ptr()
         if fuse:
             p.cd, p.cd_stride = cd.data_ptr(), cd.shape[2]
+            # small-M chains stream every weight from HBM: let each launch prefetch for the one after next (f5e_abi.h)
+            p.mall_prefetch = 1 if (M <= self.LN_FUSE_MAX_ROWS and self.mall_prefetch) else 0
         return _Plan(p, dict(arena=arena, pred=pred_t), (y, in_const, mod, eval_ptr, rope_cs, seq_len, cd), w)
 
     def forward(self, plan: "_Plan") -> Tensor:

@@ -275,6 +275,10 @@ typedef struct f5e_dit_plan {
   float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
   const float* cd;                       /* [E][mod_rows][cd_stride] f32: per block c_qkv | d_qkv | c_ff1 | d_ff1 */
   int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
+  /* batch-1 chains (fused AdaLN path): a few grid-tail workgroups of each block launch pull the weights of the launch after
+   * next into the 256 MB Infinity Cache (the 646 MB of block weights cycle through it, so every GEMM otherwise streams
+   * from HBM).  Pure performance hint: results never depend on it. */
+  int mall_prefetch;
 } f5e_dit_plan;
 
 /* Workspace planner (SURVEY 8b lower side): byte size and 256-byte-aligned offset of every caller-owned buffer of

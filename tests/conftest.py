@@ -10,3 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The oracle legs are plain PyTorch on the host: keep OpenMP inside this process's CPU share (a GPU box reports the whole
+    host's 256 logical CPUs, and 256 threads on a 16-core share make the fp32 oracle 4-5x slower)."""
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, 16)))
