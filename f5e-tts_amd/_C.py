@@ -45,6 +45,7 @@ SIGNATURES = {
     "f5e_axpby": [_P, _P, _P, _P, _F, _F, _F, _LL],
     "f5e_vq_eval": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "f5e_stft_logmel": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "f5e_stft_logmel_banded": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_istft_head": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_kaldi_fbank": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F],
     "f5e_glu": [_P, _P, _I, _P, _I, _LL, _I],

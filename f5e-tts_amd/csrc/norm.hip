@@ -64,6 +64,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
 }
 
+// Any D % 4 == 0 up to 2048 (narrow models: the reduced PPG encoder of the tests, D = 64): same arithmetic, lanes past D / 4
+// idle, up to 8 vectors per lane.  fp32 output, optional affine, no modulation.
+__global__ __launch_bounds__(256) void layernorm_any_kernel(LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* xp = a.x + (size_t)row * a.ldx;
+  const int nv = a.D / 4;
+  f32x4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < nv ? *(const f32x4*)(xp + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)a.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i * 64 + lane < nv) {
+      v[i] -= mean;
+      ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)a.D + a.eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < a.D) {
+      f32x4 y = v[i] * rstd;
+      if (a.gamma) y = y * *(const f32x4*)(a.gamma + c) + *(const f32x4*)(a.beta + c);
+      *(f32x4*)((float*)a.y + (size_t)row * a.ldy + c) = y;
+    }
+  }
+}
+
 // Head of the fused-AdaLN chain (see f5e_ln_fuse in the ABI header): no normalisation here, only the row statistics and
 // the pre-scaled bf16 copy the first consumer GEMM runs on.
 template <int VPL>
@@ -221,7 +257,6 @@ int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int
                   const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
                   int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps) {
   F5E_REQUIRE(x && y && rows > 0, "layernorm: null/empty");
-  F5E_REQUIRE(D % 256 == 0 && D >= 256 && D <= 2048, "layernorm: D=%d must be a multiple of 256 in [256, 2048]", D);
   F5E_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: ldx/ldy must be multiples of 4");
   F5E_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm: gamma and beta go together");
   F5E_REQUIRE((scale == nullptr) == (shift == nullptr), "layernorm: scale and shift go together");
@@ -229,6 +264,15 @@ int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int
   LnArgs a{x, ldx, y, ldy, y_bf16, gamma, beta, scale, shift, mod_stride, mod_rows, rows_per_seq, rows, D, eps,
            eval_ptr, eval_stride};
   const dim3 grid((rows + 3) / 4), block(256);
+  if (D % 256 != 0) {   // narrow / odd widths: plain (optionally affine) fp32 LayerNorm only
+    F5E_REQUIRE(D % 4 == 0 && D >= 4 && D <= 2048 && !scale && !y_bf16,
+                "layernorm: D=%d must be a multiple of 256 in [256, 2048] (any multiple of 4 for an fp32 LayerNorm without "
+                "modulation)", D);
+    hipLaunchKernelGGL(layernorm_any_kernel, grid, block, 0, st, a);
+    F5E_LAUNCH_CHECK("layernorm");
+    return F5E_OK;
+  }
+  F5E_REQUIRE(D % 256 == 0 && D >= 256 && D <= 2048, "layernorm: D=%d must be a multiple of 256 in [256, 2048]", D);
   switch (D / 256) {
     case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, a); break;

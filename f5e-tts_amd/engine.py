@@ -44,6 +44,8 @@ class DiTConfig:
     long_skip_connection: bool = False
     use_ppg: bool = False
     ppg_dim: int = 256
+    ppg_transformer: bool = False   # PPGEmbedding(use_transformer=True): nn.TransformerEncoder + Linear
+    ppg_heads: int = 4
 
     def validate(self) -> None:
         if self.dim_head != 64:
@@ -117,7 +119,21 @@ class DiTEngine:
         self.text_pos = text_pos_table(cfg.text_dim).to(dv) if cfg.conv_layers > 0 else None
         self.in_w, self.in_b = f("input_embed.proj.weight"), f("input_embed.proj.bias")
         self.ppg = None
-        if cfg.use_ppg:
+        if cfg.use_ppg and cfg.ppg_transformer:
+            pp = "ppg_embed.ppg_proj."
+            layers = []
+            i = 0
+            while pp + f"0.layers.{i}.self_attn.in_proj_weight" in sd:
+                q = pp + f"0.layers.{i}."
+                layers.append({k: f(q + n) for k, n in dict(
+                    w_in="self_attn.in_proj_weight", b_in="self_attn.in_proj_bias", w_o="self_attn.out_proj.weight",
+                    b_o="self_attn.out_proj.bias", w1="linear1.weight", b1="linear1.bias", w2="linear2.weight",
+                    b2="linear2.bias", g1="norm1.weight", be1="norm1.bias", g2="norm2.weight", be2="norm2.bias").items()})
+                i += 1
+            if cfg.ppg_dim % cfg.ppg_heads or (cfg.ppg_dim // cfg.ppg_heads) % 4:
+                raise _C.F5EError("PPG transformer embedding: ppg_dim / nhead must be a multiple of 4")
+            self.ppg = dict(layers=layers, w_out=f(pp + "1.weight"), b_out=f(pp + "1.bias"))
+        elif cfg.use_ppg:
             pp = "ppg_embed.ppg_proj."
             convs = []
             for ci, bi in ((2, 3), (6, 7), (10, 11)):
@@ -313,6 +329,8 @@ class DiTEngine:
         x = torch.zeros(B, N, pd, device=dv)
         if ppg is not None and not drop_ppg:
             x[:, : ppg.shape[1]] = ppg.to(dv, F32)[:, :N]
+        if cfg.ppg_transformer:
+            return self._ppg_transformer(x.view(B * N, pd), B, N)
         h = torch.empty(B * N, pd, device=dv)
         ops.gemm_f32(x.view(B * N, pd), P["w0"], P["b0"], out=h)
         col = torch.empty(B, N, 5 * pd, device=dv)
@@ -323,6 +341,41 @@ class DiTEngine:
             h = h2
         out = torch.empty(B, N, cfg.text_dim, device=dv)
         ops.gemm_f32(h, P["w15"], P["b15"], out=out.view(B * N, cfg.text_dim))
+        return out
+
+    def _ppg_transformer(self, x: Tensor, B: int, N: int) -> Tensor:
+        """PPGEmbedding(use_transformer=True) (backbones/dit.py:105-119): post-norm nn.TransformerEncoderLayer stack
+        (self-attention over the whole padded sequence, no mask, GELU(erf), LayerNorm eps 1e-5) + Linear, fp32."""
+        cfg, dv, P = self.cfg, self.device, self.ppg
+        d, H = cfg.ppg_dim, cfg.ppg_heads
+        dh = d // H
+        Np = (N + 3) // 4 * 4
+        qkv = torch.empty(B * N, 3 * d, device=dv)
+        vt = torch.zeros(d, Np, device=dv)
+        sc, pr = torch.empty(N, Np, device=dv), torch.empty(N, Np, device=dv)
+        ctx, t1 = torch.empty(B * N, d, device=dv), torch.empty(B * N, d, device=dv)
+        scale = 1.0 / math.sqrt(dh)
+        for L in P["layers"]:
+            ops.gemm_f32(x, L["w_in"], L["b_in"], out=qkv)
+            for b in range(B):
+                r0, r1 = b * N, (b + 1) * N
+                # V^T [d, N] = Wv x^T; the value bias is added after P.V (softmax rows sum to one)
+                ops.gemm_f32(L["w_in"][2 * d:], x[r0:r1], None, out=vt[:, :N])
+                for h in range(H):
+                    c0, c1 = h * dh, (h + 1) * dh
+                    ops.gemm_f32(qkv[r0:r1, c0:c1], qkv[r0:r1, d + c0:d + c1], None, out=sc[:, :N])
+                    ops.softmax_rows(sc, pr, N, scale)
+                    ops.gemm_f32(pr, vt[c0:c1], L["b_in"][2 * d + c0:2 * d + c1], out=ctx[r0:r1, c0:c1])
+            ops.gemm_f32(ctx, L["w_o"], L["b_o"], out=t1, addend=x)
+            h1 = torch.empty(B * N, d, device=dv)
+            ops.layernorm(t1, h1, gamma=L["g1"], beta=L["be1"], eps=1e-5)
+            mid = torch.empty(B * N, L["w1"].shape[0], device=dv)
+            ops.gemm_f32(h1, L["w1"], L["b1"], out=mid, act=ops.ACT_GELU_ERF)
+            ops.gemm_f32(mid, L["w2"], L["b2"], out=t1, addend=h1)
+            x = torch.empty(B * N, d, device=dv)
+            ops.layernorm(t1, x, gamma=L["g2"], beta=L["be2"], eps=1e-5)
+        out = torch.empty(B, N, cfg.text_dim, device=dv)
+        ops.gemm_f32(x, P["w_out"], P["b_out"], out=out.view(B * N, cfg.text_dim))
         return out
 
     def input_const(self, cond: Tensor, text_emb: Tensor, ppg_emb: Optional[Tensor], drop_audio_cond: bool,

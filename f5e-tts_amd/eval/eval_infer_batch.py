@@ -167,7 +167,12 @@ def main(argv=None):
     p.add_argument("-at", "--alpha_txt", default=3, type=float)
     p.add_argument("-ap", "--alpha_ppg", default=3, type=float)
     p.add_argument("-mc", "--model_cfg", default="", help="model yaml (default configs/<expname>.yaml of this package)")
-    p.add_argument("--ppg_dir", default="", help="vc mode: directory of <gen_utt>.npy PPG arrays [frames, ppg_dim]")
+    p.add_argument("--ppg_dir", default="", help="vc mode: directory of precomputed <gen_utt>.npy PPG arrays [frames, ppg_dim]; "
+                                                 "empty = extract them on the GPU with the PPG model of the model yaml")
+    p.add_argument("--source_root", default="", help="vc mode without --ppg_dir: directory with the <gen_utt>.wav source "
+                                                     "utterances whose content is converted (default: --audio_root)")
+    p.add_argument("--ppg_model", default="", help="PPG checkpoint (default: ppg_config.model_path of the model yaml)")
+    p.add_argument("--ppg_config", default="", help="PPG train.yaml (default: ppg_config.config of the model yaml)")
     args = p.parse_args(argv)
 
     import torch.distributed as dist
@@ -224,8 +229,36 @@ def main(argv=None):
             ref_len = w.getnframes() // U.hop_length
         if len(ref_txt[-1].encode("utf-8")) == 1:
             ref_txt = ref_txt + " "
-        work.append((gen_utt, ref_len, total_mel_len(ref_len, ref_txt, gen_txt)))
+        tot = total_mel_len(ref_len, ref_txt, gen_txt)
+        if args.mode == "vc" and not args.ppg_dir:
+            # voice conversion keeps the source utterance's duration (reference eval/utils_eval.py:332-336, use_truth_duration)
+            with wave.open(os.path.join(args.source_root or args.audio_root, gen_utt + ".wav"), "rb") as w:
+                tot = ref_len + int(w.getnframes() * U.target_sample_rate / w.getframerate() / U.hop_length)
+        work.append((gen_utt, ref_len, tot))
         meta[gen_utt] = (path, ref_txt, gen_txt)
+
+    ppg_front = None
+    if args.mode == "vc" and not args.ppg_dir:
+        # reference eval_infer_batch_vc.py:131-141 + :281-328: PPG of [prompt ; source] at 16 kHz from the wenet extractor
+        from ..ppg import PPGModelWapper
+        fc = mc["frontend_ppg_config"]
+        ppg_front = PPGModelWapper(args.ppg_model or fc["model_path"], args.ppg_config or fc["config"], device,
+                                   output_type=fc["output_type"], ppg_frame_length=fc["frame_length"],
+                                   mel_f_shift=fc["mel_frame_shift"], map_mix_ratio=fc["map_mix_ratio"],
+                                   global_phn_center_path=fc["global_phn_center_path"],
+                                   para_softmax_path=fc["para_softmax_path"])
+
+    def extract_ppg(utt, ref_path):
+        from ..infer import audio as A
+
+        def mono16k(path):
+            a, sr = U.load_wav(path)
+            a = a.mean(0, keepdim=True)
+            return A.resample(a, sr, 16000) if sr != 16000 else a
+
+        full = torch.cat([mono16k(ref_path), mono16k(os.path.join(args.source_root or args.audio_root, utt + ".wav"))], dim=1)
+        ppg, _len = ppg_front.audio_to_ppg(full.to(device), 16000)
+        return ppg
 
     def process_one(item):
         utt, ref_len, tot = item
@@ -246,8 +279,11 @@ def main(argv=None):
                 gen, _ = model.sample_tts(cond=ref_mel, text=text, lens=torch.tensor([ref_len]),
                                           alpha_spk=args.alpha_spk, alpha_txt=args.alpha_txt, **kw)
             else:                       # reference eval_infer_batch_vc.py:214-224
-                import numpy as np
-                ppg = torch.from_numpy(np.load(os.path.join(args.ppg_dir, utt + ".npy")).astype("float32"))[None]
+                if ppg_front is not None:
+                    ppg = extract_ppg(utt, path)
+                else:
+                    import numpy as np
+                    ppg = torch.from_numpy(np.load(os.path.join(args.ppg_dir, utt + ".npy")).astype("float32"))[None]
                 gen, _ = model.sample_vc(cond=ref_mel, ppg=ppg.to(device), alpha_spk=args.alpha_spk,
                                          alpha_ppg=args.alpha_ppg, **kw)
             wav = vocoder.decode(gen[:, ref_len:tot].permute(0, 2, 1).float())

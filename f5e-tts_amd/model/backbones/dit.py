@@ -33,13 +33,24 @@ class PPGInputTranspose(nn.Identity):
 
 
 class PPGEmbedding(nn.Module):
-    """reference backbones/dit.py:93-138, conv variant (keys ppg_proj.{0,2,3,6,7,10,11,15})."""
+    """reference backbones/dit.py:93-138: the conv variant (keys ppg_proj.{0,2,3,6,7,10,11,15}) or, with
+    ``use_transformer``, nn.TransformerEncoder + Linear (keys ppg_proj.0.layers.{i}.*, ppg_proj.1.*).  Parameter
+    containers only: the computation is engine.DiTEngine.ppg_embed on libf5e_hip.so."""
 
     def __init__(self, ppg_dim, text_dim, use_transformer=False, transformer_config=dict()):
         super().__init__()
-        if use_transformer:
-            raise _C.F5EError("the transformer PPG embedding variant is not built")
         self.ppg_dim, self.text_dim, self.use_transformer = ppg_dim, text_dim, use_transformer
+        if use_transformer:
+            import torch.nn.functional as F
+            self.nhead = transformer_config["nhead"]
+            self.ppg_proj = nn.Sequential(
+                nn.TransformerEncoder(
+                    nn.TransformerEncoderLayer(d_model=ppg_dim, nhead=transformer_config["nhead"],
+                                               dim_feedforward=transformer_config["dim_feedforward"],
+                                               dropout=transformer_config["dropout"], activation=F.gelu, batch_first=True),
+                    num_layers=transformer_config["num_layers"], enable_nested_tensor=False),
+                nn.Linear(ppg_dim, text_dim))
+            return
         layers = [nn.Linear(ppg_dim, ppg_dim), PPGInputTranspose()]
         for _ in range(3):
             layers += [nn.Conv1d(ppg_dim, ppg_dim, kernel_size=5, padding="same"), nn.BatchNorm1d(ppg_dim), nn.ReLU(),
@@ -105,7 +116,9 @@ class DiT(nn.Module):
                              text_num_embeds=text_num_embeds, text_dim=text_dim, text_mask_padding=text_mask_padding,
                              qk_norm=qk_norm, conv_layers=conv_layers, pe_attn_head=pe_attn_head,
                              long_skip_connection=long_skip_connection, use_ppg=self.use_ppg,
-                             ppg_dim=ppg_config.get("ppg_dim", 256) if self.use_ppg else 256)
+                             ppg_dim=ppg_config.get("ppg_dim", 256) if self.use_ppg else 256,
+                             ppg_transformer=bool(self.use_ppg and ppg_config.get("use_transformer", False)),
+                             ppg_heads=(ppg_config.get("transformer_config") or {}).get("nhead", 4))
         self._engine = None
         self._tensor_list = None
         self.initialize_weights()

@@ -355,6 +355,37 @@ def stft_logmel(wav: Tensor, window: Tensor, twiddle: Tensor, fb: Tensor, out: T
     return out
 
 
+def band_filterbank(fb: Tensor):
+    """Dense [n_freqs, n_mels] filterbank -> (compact weights f32 [nnz], band i32 [n_mels, 3] = lo, cnt, offset) on fb's
+    device, or None when a filter has interior zeros / the total exceeds the kernel's LDS table (dense kernel then)."""
+    h = fb.detach().to("cpu", F32)
+    nz = h != 0
+    bands, chunks, off = [], [], 0
+    for m in range(h.shape[1]):
+        idx = torch.nonzero(nz[:, m]).flatten()
+        if idx.numel() == 0:
+            bands.append((0, 0, off))
+            continue
+        lo, hi = int(idx[0]), int(idx[-1])
+        bands.append((lo, hi - lo + 1, off))       # interior zeros (if any) stay in the run: they add +0 like the dense loop
+        chunks.append(h[lo:hi + 1, m])
+        off += hi - lo + 1
+    if off == 0 or off > 2048:
+        return None
+    return torch.cat(chunks).contiguous().to(fb.device), torch.tensor(bands, dtype=I32).contiguous().to(fb.device)
+
+
+def stft_logmel_banded(wav: Tensor, window: Tensor, twiddle: Tensor, fb_compact: Tensor, fb_band: Tensor, out: Tensor,
+                       n_fft: int, hop: int):
+    require_device()
+    B, nw = wav.shape
+    check(lib().f5e_stft_logmel_banded(_stream(), _p(wav, F32, "wav"), nw, wav.stride(0), _p(window, F32, "window"),
+                                       _p(twiddle, F32, "twiddle"), _p(fb_compact, F32, "fb_compact"),
+                                       _p(fb_band, I32, "fb_band"), fb_compact.numel(), _p(out, F32, "out"), B, n_fft, hop,
+                                       fb_band.shape[0]), "f5e_stft_logmel_banded")
+    return out
+
+
 def istft_head(z: Tensor, window: Tensor, twiddle: Tensor, frames_ws: Tensor, out: Tensor, B: int, T: int, n_fft: int,
                hop: int):
     require_device()

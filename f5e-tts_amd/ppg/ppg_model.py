@@ -289,6 +289,7 @@ class ConformerEngine:
         keep_flat = keep.view(-1) if keep is not None else None
         Tp = (T2 + 3) // 4 * 4
         hn = torch.empty(M, D, device=dv)
+        hm = torch.empty(M, D, device=dv) if B > 1 else None
         units = self.layers[0]["ffm"][0].shape[0] if self.layers else D
         mid = torch.empty(M, units, device=dv)
         qu = torch.empty(M, 2 * D, device=dv)
@@ -327,12 +328,12 @@ class ConformerEngine:
             ops.gemm_f32(ctx, L["wo"], L["bo"], out=xs, addend=xs)
             # convolution module (convolution.py:84-133): mask, pointwise -> GLU -> depthwise (+BN) -> swish -> pointwise, mask
             ops.layernorm(xs, hn, gamma=ln["norm_conv"][0], beta=ln["norm_conv"][1], eps=1e-5)
-            ops.gemm_f32(hn, L["pw1"], L["pb1"], out=pw, row_scale=None)
             if keep_flat is not None:
-                # the reference zeroes padded frames BEFORE pointwise_conv1, whose bias then makes them non-zero again before
-                # the depthwise conv sees them: reproduce by computing on the masked input (row_scale on the A side is not
-                # available, so mask LN(x) first)
-                ops.gemm_f32(hn, self._eye(D), None, out=hn, row_scale=keep_flat)
+                # the reference zeroes padded frames BEFORE pointwise_conv1 (whose bias then makes them non-zero again for the
+                # depthwise conv's neighbours): mask LN(x) first (row_scale acts on the output side, hence the identity GEMM)
+                ops.gemm_f32(hn, self._eye(D), None, out=hm, row_scale=keep_flat)
+                ops.gemm_f32(hm, L["pw1"], L["pb1"], out=pw)
+            else:
                 ops.gemm_f32(hn, L["pw1"], L["pb1"], out=pw)
             ops.glu(pw, gl.view(M, D))
             ops.dwconv(gl, L["dw"], L["db"], dwo)

@@ -205,6 +205,12 @@ int f5e_vq_eval(f5e_stream st, const float* logits, int ld, const float* vars, i
  * window f32 [1024]; twiddle f32 [512][2] = (cos, -sin)(2 pi k / 1024); fb f32 [513][n_mels]. */
 int f5e_stft_logmel(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
                     const float* fb, float* out, int B, int n_fft, int hop, int n_mels);
+/* The same, bit for bit, with the filterbank handed over banded: filter m is non-zero on FFT bins [lo, lo + cnt) only
+ * (fb_band i32 [n_mels][3] = lo, cnt, offset into fb_compact; fb_compact f32 [nnz <= 2048] = those weights, filter after
+ * filter).  What MelSpec uses; the dense form above stays for arbitrary filterbanks. */
+int f5e_stft_logmel_banded(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+                           const float* fb_compact, const int* fb_band, int nnz, float* out, int B, int n_fft, int hop,
+                           int n_mels);
 /* Vocos ISTFTHead tail: z f32 [B*T][ldz] (513 log-magnitudes | 513 phases) -> out f32 [B][hop * (T - 1)];
  * frames_ws f32 [B*T][1024] scratch. */
 int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, const float* twiddle, float* frames_ws,

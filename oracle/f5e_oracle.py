@@ -186,9 +186,30 @@ def text_embedding(sd: State, text: Optional[Tensor], batch: int, seq_len: int, 
 # K17 PPG embedding                                (backbones/dit.py:93-153)
 # --------------------------------------------------------------------------
 
+def ppg_embedding_transformer(sd: State, h: Tensor, heads: int, prefix: str) -> Tensor:
+    """use_transformer=True variant (backbones/dit.py:105-119): nn.TransformerEncoder of post-norm layers (PyTorch
+    defaults: norm_first=False, eps 1e-5) with GELU(erf), batch_first, NO padding mask, then Linear(ppg_dim, text_dim)."""
+    i = 0
+    while prefix + f"0.layers.{i}.self_attn.in_proj_weight" in sd:
+        p = prefix + f"0.layers.{i}."
+        b, n, d = h.shape
+        dh = d // heads
+        q, k, v = F.linear(h, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]).chunk(3, dim=-1)
+        q, k, v = (t.view(b, n, heads, dh).transpose(1, 2) for t in (q, k, v))
+        a = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(dh), dim=-1) @ v
+        a = F.linear(a.transpose(1, 2).reshape(b, n, d), sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        h = F.layer_norm(h + a, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-5)
+        f = F.linear(F.gelu(F.linear(h, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), sd[p + "linear2.weight"],
+                     sd[p + "linear2.bias"])
+        h = F.layer_norm(h + f, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-5)
+        i += 1
+    return F.linear(h, sd[prefix + "1.weight"], sd[prefix + "1.bias"])
+
+
 def ppg_embedding(sd: State, ppg: Optional[Tensor], batch: int, seq_len: int, drop_ppg: bool,
-                  prefix: str = "ppg_embed.ppg_proj.") -> Tensor:
-    w0 = sd[prefix + "0.weight"]
+                  prefix: str = "ppg_embed.ppg_proj.", heads: int = 4) -> Tensor:
+    transformer = prefix + "0.layers.0.self_attn.in_proj_weight" in sd
+    w0 = sd[prefix + ("1.weight" if transformer else "0.weight")]
     ppg_dim = w0.shape[1]
     if ppg is None:
         h = torch.zeros((batch, seq_len, ppg_dim), dtype=w0.dtype)
@@ -196,6 +217,8 @@ def ppg_embedding(sd: State, ppg: Optional[Tensor], batch: int, seq_len: int, dr
         h = F.pad(ppg.to(w0.dtype), (0, 0, 0, seq_len - ppg.shape[1]), value=0)
         if drop_ppg:
             h = torch.zeros_like(h)
+    if transformer:
+        return ppg_embedding_transformer(sd, h, heads, prefix)
     h = F.linear(h, w0, sd[prefix + "0.bias"]).transpose(1, 2)
     for conv_i, bn_i in ((2, 3), (6, 7), (10, 11)):
         h = F.conv1d(h, sd[prefix + f"{conv_i}.weight"], sd[prefix + f"{conv_i}.bias"], padding=2)
@@ -311,7 +334,7 @@ def dit_block(sd: State, p: str, x: Tensor, t: Tensor, heads: int, mask: Optiona
 class DiTConfig:
     def __init__(self, dim=1024, depth=22, heads=16, dim_head=64, ff_mult=2, mel_dim=100, text_num_embeds=2545,
                  text_dim=512, text_mask_padding=True, qk_norm=None, conv_layers=4, pe_attn_head=None,
-                 long_skip_connection=False, use_ppg=False, ppg_dim=256, conv_groups=16):
+                 long_skip_connection=False, use_ppg=False, ppg_dim=256, conv_groups=16, ppg_heads=4):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -337,7 +360,7 @@ def dit_sample(sd: State, cfg: DiTConfig, x: Tensor, cond: Tensor, text: Optiona
         text_emb = text_embedding(sd, text, b, n, drop_text, mask_padding=cfg.text_mask_padding)
         if cache is not None:
             cache[key] = text_emb
-    ppg_emb = ppg_embedding(sd, ppg, b, n, drop_ppg) if cfg.use_ppg else None
+    ppg_emb = ppg_embedding(sd, ppg, b, n, drop_ppg, heads=getattr(cfg, "ppg_heads", 4)) if cfg.use_ppg else None
     h = input_embedding(sd, x, cond, text_emb, ppg_emb, drop_audio_cond)
     inv = sd.get("rotary_embed.inv_freq")
     freqs = rope_freqs(n, cfg.dim_head, inv)

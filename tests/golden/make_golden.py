@@ -474,6 +474,24 @@ def make_vq_case(modules_mod):
     print("wrote", path)
 
 
+def make_ppg_embed_transformer_case(dit_mod):
+    """The ``use_transformer=True`` PPGEmbedding of the reference (backbones/dit.py:105-119) on seeded weights."""
+    torch.manual_seed(909)
+    m = dit_mod.PPGEmbedding(ppg_dim=32, text_dim=48, use_transformer=True,
+                             transformer_config=dict(nhead=4, dim_feedforward=64, dropout=0.1, num_layers=2)).eval()
+    g = torch.Generator().manual_seed(910)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+        ppg = torch.randn(2, 9, 32, generator=g)
+        out = {"ppg": ppg, "out": m(ppg, 14), "out_drop": m(ppg, 14, drop_ppg=True), "out_none": m(None, 14, batch=2)}
+    out.update(_sd(m))
+    path = os.path.join(HERE, "ppg_embed_transformer.npz")
+    np.savez_compressed(path, **_np(out))
+    print("wrote", path, tuple(out["out"].shape))
+
+
 def make_stft_case(ref_root):
     """Pins for the transform part of a14 (log-mel front-end) and a17 (Vocos iSTFT head) from REFERENCE-HELD code:
     the reference restates both as convolutions for its ONNX export -- ``runtime/triton_trtllm/scripts/conv_stft.py``
@@ -613,6 +631,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "unett":
         make_unett_case()
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "ppgtr":
+        make_ppg_embed_transformer_case(dit_mod)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "stft":
         make_stft_case(ref)
         return
@@ -635,6 +656,7 @@ def main():
     make_vq_case(modules_mod)
     make_unett_case()
     make_stft_case(ref)
+    make_ppg_embed_transformer_case(dit_mod)
     make_ppg_case(ref)
     make_layouts(dit_mod)
 

@@ -226,6 +226,36 @@ def test_three_branch_samplers_with_ppg():
     assert rel_l2(t[-1], rt[-1]) < 2e-2, rel_l2(t[-1], rt[-1])
 
 
+def test_ppg_embedding_transformer_variant():
+    """PPGEmbedding(use_transformer=True) (reference backbones/dit.py:105-119: nn.TransformerEncoder + Linear) through the
+    sampler: sample_vc / sample with PPG against the oracle (itself pinned by tests/golden/ppg_embed_transformer.npz)."""
+    from f5e_tts_amd.model import CFM, DiT
+    arch = dict(dim=1024, depth=2, heads=16, ff_mult=2, text_dim=256, conv_layers=2, text_num_embeds=300)
+    cfg = SY.DiTConfig(**arch, use_ppg=True, ppg_dim=256, text_mask_padding=False, ppg_transformer=True, ppg_heads=4,
+                       ppg_ff=512, ppg_layers=2)
+    ocfg = O.DiTConfig(**arch, use_ppg=True, ppg_dim=256, text_mask_padding=False, ppg_heads=4)
+    sd = SY.init_dit_state(cfg, 31)
+    ppg_config = dict(use_ppg=True, ppg_dim=256, use_transformer=True,
+                      transformer_config=dict(num_layers=2, nhead=4, dim_feedforward=512, dropout=0.1))
+    dit = DiT(**arch, text_mask_padding=False, ppg_config=ppg_config)
+    dit.load_state_dict(sd, strict=True)
+    cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
+    g = torch.Generator().manual_seed(19)
+    cond, ppg = torch.randn(2, 30, 100, generator=g), torch.randn(2, 41, 256, generator=g)
+    text = torch.randint(0, 300, (2, 10), generator=g)
+    kw = dict(duration=torch.tensor([77, 70]), lens=torch.tensor([30, 27]), steps=3, sway_sampling_coef=-1.0, seed=2)
+    # the embedding alone, fp32 both sides
+    emb = dit.engine().ppg_embed(ppg.cuda(), 2, 77, False)
+    ref_emb = O.ppg_embedding(sd, ppg, 2, 77, False, heads=4)
+    assert rel_l2(emb, ref_emb) < 1e-4, rel_l2(emb, ref_emb)
+    o, t = cfm.sample_vc(cond.cuda(), ppg.cuda(), alpha_spk=2.5, alpha_ppg=3.0, **kw)
+    ro, rt = O.cfm_sample(sd, ocfg, cond, None, ppg, mode="vc", alpha_a=2.5, alpha_b=3.0, **kw)
+    assert rel_l2(t[-1], rt[-1]) < 2e-2, rel_l2(t[-1], rt[-1])
+    o, t = cfm.sample(cond.cuda(), text.cuda(), ppg.cuda(), cfg_strength=2.0, **kw)
+    ro, rt = O.cfm_sample(sd, ocfg, cond, text, ppg, cfg_strength=2.0, **kw)
+    assert rel_l2(t[-1], rt[-1]) < 2e-2, rel_l2(t[-1], rt[-1])
+
+
 def test_small_ppg_config_c5_shape():
     """BASELINE config 5 architecture (reference configs/example.yaml: dim 768 -> 48 channels per conv-pos group,
     12 heads, pe_attn_head 1, no text mask padding, PPG input) at reduced depth; plus qk_norm and long skip."""

@@ -369,6 +369,22 @@ def test_stft_logmel(ops, B, frames):
     close(out, ref, 1e-4, 2e-4, "log-mel")  # log of a sum of |X|: fp32 FFT ordering differences only
 
 
+def test_stft_logmel_banded_is_bit_identical_to_dense(ops):
+    """The banded log-mel kernel (filter runs from LDS) must reproduce the dense kernel bit for bit: same products, same
+    ascending-bin summation order, the skipped terms are exact zeros."""
+    from f5e_tts_amd.engine import mel_filterbank
+    wav = SY.synthetic_ref_wave(375, batch=3)
+    win, tw = fft_tables()
+    fb = dev(mel_filterbank(513, 100, 24000))
+    band = ops.band_filterbank(fb)
+    assert band is not None and band[0].numel() <= 2048 and band[1].shape == (100, 3)
+    assert float(band[0].sum()) == pytest.approx(float(fb.sum()), rel=1e-6)
+    dense, banded = torch.empty(3, 375, 100, device="cuda"), torch.empty(3, 375, 100, device="cuda")
+    ops.stft_logmel(dev(wav), dev(win), dev(tw), fb, dense, 1024, 256)
+    ops.stft_logmel_banded(dev(wav), dev(win), dev(tw), band[0], band[1], banded, 1024, 256)
+    assert torch.equal(dense, banded)
+
+
 @pytest.mark.parametrize("B,T", [(1, 281), (2, 9)])
 def test_istft_head(ops, B, T):
     z = torch.randn(B * T, 1026, generator=g(47))

@@ -201,3 +201,14 @@ def test_oracle_istft_head_matches_reference_istft_head(tag):
         env = env[512: 512 + 256 * (T - 1)]
         for b in range(1, z.shape[0]):
             assert float((audio[b] * env - common[b]).abs().max()) < 2e-4 * float(common[b].abs().max())
+
+
+def test_ppg_embedding_transformer_variant_matches_reference():
+    """PPGEmbedding(use_transformer=True) (backbones/dit.py:105-119) against the reference class's own outputs."""
+    z = np.load(os.path.join(GOLD, "ppg_embed_transformer.npz"), allow_pickle=False)
+    sd = {"ppg_embed." + k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    ppg = torch.from_numpy(z["ppg"])
+    for drop, key in ((False, "out"), (True, "out_drop")):
+        got = O.ppg_embedding(sd, ppg, 2, 14, drop, heads=4)
+        torch.testing.assert_close(got, torch.from_numpy(z[key]), **TOL)
+    torch.testing.assert_close(O.ppg_embedding(sd, None, 2, 14, False, heads=4), torch.from_numpy(z["out_none"]), **TOL)

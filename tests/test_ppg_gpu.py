@@ -1,0 +1,181 @@
+"""PPG extractor on the GPU: f5e_tts_amd.ppg -> libf5e_hip.so against
+  * the REFERENCE's outputs directly (tests/golden/ppg_conformer.npz: ASRModel.extract + PPGModelWapper.mel_to_ppg of the
+    reference's own classes on seeded weights), and
+  * the CPU oracle (oracle/f5e_ppg_oracle.py, pinned by the same fixture) at the default encoder size.
+fp32 on both sides (exact-fp32 MFMA GEMMs); tolerances cover summation order through 6-12 conformer layers."""
+import math
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import f5e_ppg_oracle as P
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def fixture():
+    z = np.load(os.path.join(GOLD, "ppg_conformer.npz"), allow_pickle=False)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    g = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("w/")}
+    return sd, g
+
+
+def seeded_state(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = 1.0 + 0.2 * torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean") or k.endswith("global_cmvn.mean"):
+            sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith("global_cmvn.istd"):
+            sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif v.ndim == 1:
+            base = 1.0 if ("norm" in k and k.endswith("weight")) else 0.0
+            sd[k] = base + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            fan_in = v[0].numel()
+            sd[k] = (torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    return sd
+
+
+def test_conformer_matches_the_reference_fixture():
+    """Same weights, same features as the reference run: ppg, logits and the mel_to_ppg target."""
+    from f5e_tts_amd.ppg import ConformerPPG, PPGModelWapper
+    sd, g = fixture()
+    m = ConformerPPG(80, 40, 64, 4, 128, 2, 15, global_cmvn=(sd["encoder.global_cmvn.mean"], sd["encoder.global_cmvn.istd"]))
+    full = m.state_dict()
+    full.update({k: v for k, v in sd.items() if k in full})
+    m.load_state_dict(full)
+    m = m.cuda().eval()
+    ppg, logits = m.extract(g["feats"].cuda(), g["lens"].cuda())
+    valid = torch.arange(50)[None, :] < torch.tensor([50, 38])[:, None]
+    e = rel_l2(ppg.cpu()[valid], g["ppg"][valid])
+    print("ppg vs reference rel L2 %.2e" % e)
+    assert e < 2e-4
+    assert rel_l2(logits.view(2, 50, -1).cpu()[valid], g["logits"].view(2, 50, -1)[valid]) < 2e-4
+    wrap = object.__new__(PPGModelWapper)
+    wrap.ppg_model, wrap.output_type, wrap.map_mix_ratio = m, "ppg", 1.0
+    wrap.ppg_frame_length, wrap.mel_f_shift, wrap.device = 20, 10, "cuda"
+    tgt, true_len = wrap.mel_to_ppg(g["feats"].cuda(), g["lens"])
+    assert true_len.tolist() == g["true_len"].tolist() == [50, 38]
+    assert rel_l2(tgt, g["target"]) < 2e-4 and float(tgt[1, 38:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,T", [(1, 501), (2, 240)])
+def test_default_size_conformer_vs_oracle(B, T):
+    """The encoder at its constructor defaults (256-d, 4 heads, 2048 units, 6 blocks, kernel 15; asr_model.py:829-836) --
+    what a real PPG checkpoint of the reference uses apart from the block count -- on 5 s / ragged 2.4 s of features."""
+    from f5e_tts_amd.ppg import ConformerPPG
+    g = torch.Generator().manual_seed(7)
+    m = ConformerPPG(80, 218, global_cmvn=(torch.zeros(80), torch.ones(80)))
+    sd = seeded_state(m, 11)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    feats = 3.0 * torch.randn(B, T, 80, generator=g) + 6.0
+    lens = torch.tensor([T, T - 61][:B])
+    if B > 1:
+        feats[1, T - 61:] = 0.0
+    ref, ref_logits = P.asr_extract(sd, feats, lens, heads=4)
+    ppg, logits = m.extract(feats.cuda(), lens)
+    T2 = (T - 3) // 2 + 1
+    valid = torch.arange(T2)[None, :] < torch.tensor([T2, (T - 61 + 1) // 2][:B])[:, None]
+    e = rel_l2(ppg.cpu()[valid], ref[valid])
+    print("B=%d T=%d: ppg rel L2 %.2e" % (B, T, e))
+    assert ppg.shape == ref.shape == (B, T2, 256) and e < 5e-4
+    assert rel_l2(logits.view(B, T2, -1).cpu()[valid], ref_logits.view(B, T2, -1)[valid]) < 5e-4
+
+
+def test_kaldi_fbank_kernel_vs_oracle():
+    from f5e_tts_amd.ppg import kaldiFbank
+    g = torch.Generator().manual_seed(3)
+    wav = 0.05 * torch.randn(2, 16000 * 2 + 123, generator=g)
+    wav[1] += 0.02                                            # DC offset: removed per frame
+    feats, n = kaldiFbank()(wav.cuda())
+    ref = torch.stack([P.kaldi_fbank(wav[i]) for i in range(2)])
+    assert feats.shape == ref.shape == (2, 1 + (wav.shape[1] - 400) // 160, 80) and int(n) == ref.shape[1]
+    # log of an 80-bin sum of power spectra (values ~ 8..14): fp32 FFT ordering differences only
+    torch.testing.assert_close(feats.cpu(), ref, rtol=2e-4, atol=2e-3)
+
+
+def test_wrapper_from_files_and_map_mode(tmp_path):
+    """build_ppg_model / PPGModelWapper from a yaml + checkpoint + kaldi-text cmvn on disk (reference ppg_model.py:11-29,
+    58-100), audio_to_ppg on a 24 kHz wave (resampled to 16 kHz), and the "map" output (softmax over phone centres)."""
+    import yaml
+
+    from f5e_tts_amd.infer import audio as A
+    from f5e_tts_amd.ppg import ConformerPPG, PPGModelWapper, load_cmvn
+    g = torch.Generator().manual_seed(5)
+    count = 1000.0
+    mean, var = 8.0 + torch.randn(80, generator=g), 4.0 + torch.rand(80, generator=g)
+    stats = [" ".join("%.6f" % float(v * count) for v in mean) + " %.1f" % count,
+             " ".join("%.6f" % float((var[i] + mean[i] ** 2) * count) for i in range(80)) + " 0"]
+    (tmp_path / "global_cmvn").write_text("[ " + stats[0] + "\n" + stats[1] + " ]\n")
+    cfg = dict(cmvn_file=str(tmp_path / "missing_dir" / "global_cmvn"), is_json_cmvn=False, input_dim=80, output_dim=60,
+               encoder="conformer", encoder_conf=dict(output_size=64, attention_heads=4, linear_units=128, num_blocks=2,
+                                                      input_layer="conv2d", pos_enc_layer_type="rel_pos"),
+               decoder="transformer", decoder_conf=dict(num_blocks=1), model_conf=dict(sv_conf=dict(use_sv=False)))
+    (tmp_path / "train.yaml").write_text(yaml.safe_dump(cfg))
+    m, istd = load_cmvn(str(tmp_path / "global_cmvn"), False)
+    proto = ConformerPPG(80, 60, 64, 4, 128, 2, 15, global_cmvn=(torch.from_numpy(m).float(), torch.from_numpy(istd).float()))
+    sd = seeded_state(proto, 21)
+    sd["encoder.global_cmvn.mean"], sd["encoder.global_cmvn.istd"] = torch.from_numpy(m).float(), torch.from_numpy(istd).float()
+    ckpt = dict(sd)
+    ckpt["decoder.embed.0.weight"] = torch.zeros(3, 3)        # keys outside extract() are ignored, as in the reference
+    torch.save(ckpt, str(tmp_path / "33.pt"))
+    np.save(str(tmp_path / "phn_center.npy"), torch.randn(30, 64, generator=g).numpy())
+    para = {"w": torch.randn(30, 64, generator=g).numpy(), "b": torch.randn(30, generator=g).numpy()}
+    pickle.dump(para, open(str(tmp_path / "21pt.pkl"), "wb"))
+    wav24 = 0.05 * torch.randn(1, 24000 * 2, generator=g)
+    feats16 = P.kaldi_fbank(A.resample(wav24, 24000, 16000)[0])[None]
+    lens = torch.tensor([feats16.shape[1]])
+    for mode in ("ppg", "map"):
+        w = PPGModelWapper(str(tmp_path / "33.pt"), str(tmp_path / "train.yaml"), "cuda", output_type=mode,
+                           global_phn_center_path=str(tmp_path / "phn_center.npy"),
+                           para_softmax_path=str(tmp_path / "21pt.pkl"))
+        ppg, true_len = w.audio_to_ppg(wav24, 24000)
+        ref, ref_len = P.mel_to_ppg(sd, feats16, lens, heads=4)
+        if mode == "map":      # reference ppg_model.py:116-125
+            soft = (ref @ torch.from_numpy(para["w"]).T + torch.from_numpy(para["b"])).softmax(-1)
+            ref = soft @ torch.from_numpy(np.load(str(tmp_path / "phn_center.npy")))
+        assert true_len.tolist() == ref_len.tolist() and ppg.shape == ref.shape
+        e = rel_l2(ppg, ref)
+        print(mode, "rel L2 %.2e" % e)
+        assert e < 2e-3        # includes the fbank kernel (log features) in front of the encoder
+
+
+def test_ppg_feeds_sample_vc():
+    """The extractor's output is what CFM.sample_vc consumes (reference eval_infer_batch_vc.py:208-224): shapes and frame
+    rate line up (20 ms PPG frames vs 10.67 ms mel frames: ppg length ~ 0.533 N) and the sampler runs on it."""
+    from f5e_tts_amd.model import CFM, DiT
+    from f5e_tts_amd.ppg import ConformerPPG, kaldiFbank
+    from tools import synth as SY
+    cfg = SY.DiTConfig(dim=768, depth=2, heads=12, ff_mult=2, text_dim=512, conv_layers=2, text_num_embeds=300,
+                       text_mask_padding=False, pe_attn_head=1, use_ppg=True, ppg_dim=256)
+    ppg_config = dict(use_ppg=True, ppg_dim=256, use_transformer=False)
+    dit = DiT(dim=768, depth=2, heads=12, ff_mult=2, text_dim=512, conv_layers=2, text_num_embeds=300,
+              text_mask_padding=False, pe_attn_head=1, ppg_config=ppg_config)
+    dit.load_state_dict(SY.init_dit_state(cfg, 8), strict=True)
+    cfm = CFM(transformer=dit, ppg_config=ppg_config).cuda().eval()
+    m = ConformerPPG(80, 218, num_blocks=2)
+    m.load_state_dict(seeded_state(m, 12))
+    m = m.cuda().eval()
+    n_ref, n = 94, 281                                           # 1 s prompt, 3 s total at 24 kHz / hop 256
+    wav16 = 0.05 * torch.randn(1, 16000 * 3, generator=torch.Generator().manual_seed(2))
+    feats, flen = kaldiFbank()(wav16.cuda())
+    ppg, _ = m.extract(feats, flen)
+    assert abs(ppg.shape[1] - round(0.533 * n)) <= 3
+    out, _ = cfm.sample_vc(SY.synthetic_ref_wave(n_ref).cuda(), ppg, duration=n, steps=4, alpha_spk=2.5, alpha_ppg=3.0,
+                           sway_sampling_coef=-1.0, seed=0)
+    assert out.shape == (1, n, 100) and torch.isfinite(out).all()

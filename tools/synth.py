@@ -23,7 +23,8 @@ class DiTConfig:
 
     def __init__(self, dim=1024, depth=22, heads=16, dim_head=64, ff_mult=2, mel_dim=100, text_num_embeds=2545,
                  text_dim=512, text_mask_padding=True, qk_norm=None, conv_layers=4, pe_attn_head=None,
-                 long_skip_connection=False, use_ppg=False, ppg_dim=256, conv_groups=16):
+                 long_skip_connection=False, use_ppg=False, ppg_dim=256, conv_groups=16, ppg_transformer=False,
+                 ppg_heads=4, ppg_ff=512, ppg_layers=2):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -64,7 +65,20 @@ def init_dit_state(cfg, seed: int = 1234, std_zeroed: float = 0.02) -> State:
         sd[p + "grn.gamma"] = 0.1 * torch.randn((1, 1, 2 * td), generator=g)
         sd[p + "grn.beta"] = 0.1 * torch.randn((1, 1, 2 * td), generator=g)
         lin(p + "pwconv2", td, 2 * td)
-    if cfg.use_ppg:
+    if cfg.use_ppg and getattr(cfg, "ppg_transformer", False):   # PPGEmbedding(use_transformer=True), dit.py:105-119
+        pd, pp = cfg.ppg_dim, "ppg_embed.ppg_proj."
+        for i in range(cfg.ppg_layers):
+            q = pp + f"0.layers.{i}."
+            sd[q + "self_attn.in_proj_weight"] = uni((3 * pd, pd), pd)
+            sd[q + "self_attn.in_proj_bias"] = uni((3 * pd,), pd)
+            lin(q + "self_attn.out_proj", pd, pd)
+            lin(q + "linear1", cfg.ppg_ff, pd)
+            lin(q + "linear2", pd, cfg.ppg_ff)
+            for n_ in ("norm1", "norm2"):
+                sd[q + n_ + ".weight"] = 1.0 + 0.1 * torch.randn((pd,), generator=g)
+                sd[q + n_ + ".bias"] = 0.1 * torch.randn((pd,), generator=g)
+        lin(pp + "1", td, pd)
+    elif cfg.use_ppg:
         pd = cfg.ppg_dim
         pp = "ppg_embed.ppg_proj."
         lin(pp + "0", pd, pd)
