@@ -21,6 +21,7 @@
 // batch 1 (N = 469: 15 q-tiles x 32 (s, head) x 4 splits = 1920 waves).
 //   S^T = K . Q^T  (lane-local softmax statistics),  O^T = V^T . P^T with P taken from the S^T accumulator registers
 //   (cdna guide section 3 "An accumulator tile as the next MFMA's operand").
+#include <cstdlib>
 #include "f5e_common.h"
 
 namespace {
@@ -254,9 +255,11 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
 // kernel once S*H*N^2 is large (C3: 7.4 GB of L2 reads per call).  The fragment-major K / V tiles are contiguous in
 // memory (K: 2 x 4 KiB, V: 2 x 4 KiB per 64 keys), so the DMA is a linear copy and a fragment read is
 // ds_read_b128 at fragment*1 KiB + (lane&31)*32 + (lane>>5)*16 (2-way bank conflict, LDS is far from saturated).
-__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
+// NST = ring depth (48 / 32 KiB of LDS -> 3 / 5 workgroups per CU by LDS), OCC = waves per SIMD the register allocation must
+// leave room for (__launch_bounds__ second argument: 4 -> <= 128 VGPRs, 5 -> <= 96).
+template <int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   constexpr int TILE_BYTES = 16384;  // K 8 KiB + V 8 KiB per 64 keys
-  constexpr int NST = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -308,13 +311,14 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   if (ntiles > 0) stage(0, 0);
-  if (ntiles > 1) stage(1, 1);
-  int buf = 0, nbuf = 2;
+  if (NST > 2 && ntiles > 1) stage(1, 1);
+  int buf = 0, nbuf = NST - 1;
   for (int t64 = 0; t64 < ntiles; ++t64) {
-    if (t64 + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    // tile t64 landed (NST - 2 younger tiles of 4 DMAs each may stay in flight), every wave done reading tile t64 - 1
+    if (NST > 2 && t64 + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t64 + 2 < ntiles) stage(nbuf, t64 + 2);
+    if (t64 + NST - 1 < ntiles) stage(nbuf, t64 + NST - 1);
     const char* Ks = smem + buf * TILE_BYTES;
     const char* Vs = Ks + 8192;
 
@@ -418,7 +422,11 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
   // LDS-free kernel would already have >= 8 waves per CU without any KV split)
   if (splits == -1 || (splits == 0 && grid >= 8192)) {
     const int g128 = ((rows_per_seq + 127) / 128) * H * S;
-    hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(g128), dim3(256), 3 * 16384, st, a);
+    static const int variant = getenv("F5E_ATTN_VARIANT") ? atoi(getenv("F5E_ATTN_VARIANT")) : 0;   // tuning switch
+    if (variant == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
+    else if (variant == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 5>), dim3(g128), dim3(256), 2 * 16384, st, a);
+    else if (variant == 3) hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 3>), dim3(g128), dim3(256), 3 * 16384, st, a);
+    else hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 4>), dim3(g128), dim3(256), 3 * 16384, st, a);
     F5E_LAUNCH_CHECK("flash_attn_lds");
     return F5E_OK;
   }

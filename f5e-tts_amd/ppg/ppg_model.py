@@ -168,7 +168,7 @@ class ConformerPPG(nn.Module):
         if self._engine is None or self._engine.device != dev:
             if dev.type != "cuda":
                 raise _C.F5EError(f"PPG model lives on {dev}: move it to the GPU (there is no CPU path)")
-            self._engine = ConformerEngine(self.state_dict(), self.heads, dev)
+            self._engine = ConformerEngine(self.state_dict(), self.heads, dev, self.input_dim)
         return self._engine
 
     @torch.no_grad()
@@ -183,7 +183,7 @@ class ConformerPPG(nn.Module):
 class ConformerEngine:
     """Repacked fp32 weights + the launch sequence of ``BaseEncoder.forward`` (wenet/transformer/encoder.py:141-209)."""
 
-    def __init__(self, sd: Dict[str, Tensor], heads: int, device):
+    def __init__(self, sd: Dict[str, Tensor], heads: int, device, idim: int):
         ops.require_device()
         self.device = dv = torch.device(device)
         f = lambda k: sd[k].detach().to(dv, F32).contiguous()   # noqa: E731
@@ -193,8 +193,9 @@ class ConformerEngine:
         ow = f("encoder.embed.out.0.weight")                                             # [D, C * F2]
         self.dim = D = ow.shape[0]
         F2 = ow.shape[1] // C
-        self.idim = idim = 2 * F2 + 1 if "encoder.global_cmvn.mean" not in sd else sd["encoder.global_cmvn.mean"].numel()
-        assert (idim - 1) // 2 == F2
+        self.idim = idim
+        if (idim - 1) // 2 != F2:
+            raise _C.F5EError(f"PPG extractor: embed.out expects {F2} subsampled bins, input_dim {idim} gives {(idim - 1) // 2}")
         # Conv2d(1, C, 3, stride 2) over [T, idim] as ONE dense GEMM per frame triple: row n = c * F2 + f' of a Toeplitz
         # matrix holds w[c, 0, i, j] at column i * idim + 2 f' + j.  Global CMVN ((x - mean) * istd, per feature) is
         # linear in x, so it folds into these weights and a per-row bias (weights-only transform, done once).
