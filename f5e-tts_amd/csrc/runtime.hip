@@ -2,6 +2,7 @@
 // that chains the per-op kernels for one network call (reference backbones/dit.py:452-470, model/modules.py:627-641).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "f5e_common.h"
 
@@ -221,6 +222,9 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     // Infinity-Cache prefetch (f5e_common.h): every GEMM / attention launch of a block drags the weights of the launch after
     // next into the memory-side cache with a few grid-tail workgroups, so the batch-1 GEMMs stop waiting for HBM.
     const bool pfon = p->mall_prefetch != 0;
+    // which launch hosts the 6 MB of the NEXT block's QKV weights: FF2 (one workgroup per CU at batch 1: room for the extra
+    // ones) rather than FF1 (two per CU: hosting there cost it +1 us).  F5E_PF_SCHEME=0 restores FF1 (A/B switch).
+    static const int pf_scheme = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : 1;
     const unsigned b_out = (unsigned)((size_t)D * inner * 2), b_ff = (unsigned)((size_t)p->FF * D * 2);
     const unsigned b_qkv = (unsigned)((size_t)3 * inner * D * 2);
     for (int l = 0; l < p->L; ++l) {
@@ -243,12 +247,12 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
                                           inner, 0, &prod, pfon ? &pf_out : nullptr));
       cons.c = cdl + 6 * inner; cons.d = cdl + 6 * inner + p->FF;
       F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_pf(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
-                                    F5E_ACT_GELU_TANH, 0, 0, &cons, pfon ? &pf_ff1 : nullptr));
+                                    F5E_ACT_GELU_TANH, 0, 0, &cons, (pfon && pf_scheme == 0) ? &pf_ff1 : nullptr));
       // next norm: attn_norm of block l+1 (scale_msa at +D) or the final AdaLN (scale first: modules.py:333)
       prod.next_scale = (l + 1 < p->L) ? mb + 6 * D + D : p->mod + (size_t)p->L * 6 * D;
-      F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_ln(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,
+      F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_pf(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,
                                           row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF,
-                                          0, &prod));
+                                          0, &prod, (pfon && pf_scheme != 0) ? &pf_ff1 : nullptr));
     }
     cons.c = p->cd + (size_t)p->L * ls; cons.d = cons.c + p->mel;
     F5E_TIMED(F5E_OP_FINAL, f5e_gemm_bf16_bias_ln(st, p->hn, D, p->w_proj, D, nullptr, p->pred, p->mel, M, p->mel, D,
