@@ -422,11 +422,13 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
   // LDS-free kernel would already have >= 8 waves per CU without any KV split)
   if (splits == -1 || (splits == 0 && grid >= 8192)) {
     const int g128 = ((rows_per_seq + 127) / 128) * H * S;
-    static const int variant = getenv("F5E_ATTN_VARIANT") ? atoi(getenv("F5E_ATTN_VARIANT")) : 0;   // tuning switch
-    if (variant == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
-    else if (variant == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 5>), dim3(g128), dim3(256), 2 * 16384, st, a);
-    else if (variant == 3) hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 3>), dim3(g128), dim3(256), 3 * 16384, st, a);
-    else hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 4>), dim3(g128), dim3(256), 3 * 16384, st, a);
+    // Ring depth / occupancy (C3, us per launch): 3 stages = 48 KiB -> 3 workgroups per CU 324; 2 stages = 32 KiB -> 4 per CU
+    // (VGPR-limited) 292; forcing 5 per CU (<= 96 VGPRs, 3 spilled) 300.  The softmax is VALU-bound: more resident waves
+    // beat a deeper prefetch.  F5E_ATTN_VARIANT=3 restores the 3-stage ring (A/B switch).
+    static const int variant = getenv("F5E_ATTN_VARIANT") ? atoi(getenv("F5E_ATTN_VARIANT")) : 1;
+    if (variant == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 5>), dim3(g128), dim3(256), 2 * 16384, st, a);
+    else if (variant == 3) hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 4>), dim3(g128), dim3(256), 3 * 16384, st, a);
+    else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
     F5E_LAUNCH_CHECK("flash_attn_lds");
     return F5E_OK;
   }

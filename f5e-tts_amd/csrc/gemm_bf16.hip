@@ -501,7 +501,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   if (a.ln_stats || a.stats_out) {  // fused AdaLN: 64x64 tiles (small M) or the 256x256 ping-pong kernel (large M)
     F5E_REQUIRE(!(a.ln_stats && a.stats_out), "gemm_bf16: a launch is an AdaLN consumer or a producer, not both");
     F5E_REQUIRE(!(EPI == EPI_QKV_ROPE && a.qn_w), "gemm_bf16: fused AdaLN and qk_norm need different tiles");
-    if (sel == 9 || (tile_hint == 0 && a.K >= 128 && (a.M + 255) / 256 >= 44)) return launch_pp(EPI, a, st, 0);
+    if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, 0);
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
@@ -514,7 +514,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip); hint 9 forces it (tests / tuning).  Crossover against the
   // 128x128 ring kernel measured on the four DiT shapes (tools/gemm_tune.py M 21,9): M = 7.5k ring kernel ahead by 0-40 %,
   // M = 13k ping-pong ahead by 5-18 %, M = 30k by 8-37 %: it takes over at 44 row tiles of 256, whatever N.
-  if (sel == 9 || (tile_hint == 0 && a.K >= 128 && (a.M + 255) / 256 >= 44)) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
+  if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
@@ -572,6 +572,7 @@ int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
   a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;
   a.cd_rows = ln->cd_rows; a.cd_eval_stride = ln->cd_eval_stride; a.ln_eps = ln->eps;
   a.eval_ptr = ln->eval_ptr;
+  a.ln_rowstats = ln->row_stats;
   if (a.rows_per_seq <= 0) a.rows_per_seq = ln->rows_per_seq;
   return F5E_OK;
 }

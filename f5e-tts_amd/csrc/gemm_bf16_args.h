@@ -40,6 +40,7 @@ struct GemmArgs {
   //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
   //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
   const float* ln_stats; int ln_parts;
+  const float* ln_rowstats;   // large-M consumer (gemm_bf16_pp.hip): [M + 1][2] = (mean, rstd) from f5e_ln_finalize
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
   int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
@@ -70,5 +71,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 
 // gemm_bf16_pp.hip: 256x256 tile, 8 waves in two staggered groups (defined there; epi = EPI_* id)
 int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg = 0);  // dbg 1..3: timing ablations (garbage results)
+// the rule both the dispatcher and f5e_dit_forward use: launches of this many rows take the 256x256 kernel
+inline bool uses_pp(int M, int K) { return K >= 128 && (M + 255) / 256 >= 44; }
 
 }  // namespace f5e_gemm

@@ -127,6 +127,20 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
         wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
   };
 
+  if constexpr (FUSE == 1) {
+    // fused-AdaLN consumer operands, fetched now and used in the epilogue: waves 0-1 the (mean, rstd) pairs of rows
+    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  They are
+    // the OLDEST vector-memory operations of their waves, so every counted wait of the main loop retires them first.
+    char* lnb = smem + 8 * HALF_BYTES;
+    if (wave < 2) {
+      const int r = min(m0 + wave * 128 + lane * 2, a.M - 1);
+      glds16(a.ln_rowstats + (size_t)r * 2, lnb + wave * 1024);
+    } else if (wave < 4) {
+      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+      const int n = min(n0 + lane * 4, a.N - 4);
+      glds16((wave == 2 ? a.ln_c : a.ln_d) + eoff + n, lnb + 2048 + (wave - 2) * 1024);
+    }
+  }
   // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
 #pragma unroll
   for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
@@ -199,51 +213,23 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   char* reg = smem + wave * 16384;
   const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
   if constexpr (FUSE == 1) {
-    // Row statistics of this wave's 128 rows: lane l combines the `ln_parts` (mean, M2) tile partials of rows l and l + 64
-    // (Chan's formula, fixed order: identical to the 64 x 64 kernel), parks (mean, rstd) in the first KiB of the wave's
-    // LDS region; then the accumulators are normalised in place, so every epilogue below runs unchanged with bias = NULL
-    // (d carries it).
-    const int pp4 = a.ln_parts >> 2;   // f32x4 loads per row: (mean, M2) x 2 each
-    float* mr = (float*)reg;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = h * 64 + lane;
-      const float* sp = a.ln_stats + (size_t)min(mbase + r, a.M - 1) * a.ln_parts * 2;
-      f32x4 pq[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pq[u] = *(const f32x4*)(sp + 4 * min(u, 2 * pp4 - 1));
-      float sm = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (u < 2 * pp4) sm += pq[u][0] + pq[u][2];
-      const float mean = sm / (float)a.ln_parts;
-      const float cols = (float)(a.K / a.ln_parts);
-      float m2 = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (u < 2 * pp4) {
-          const float d0 = pq[u][0] - mean, d1 = pq[u][2] - mean;
-          m2 += (pq[u][1] + cols * d0 * d0) + (pq[u][3] + cols * d1 * d1);
-        }
-      *(f32x2*)(mr + r * 2) = f32x2{mean, rsqrtf(m2 / (float)a.K + a.ln_eps)};
-    }
-    const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+    // (mean, rstd) of the tile's 256 rows and c / d of its 256 columns were LDS-DMA'd into the 4 KiB behind the ring at
+    // the top of this tile (below): no memory round trip here.  The accumulators are normalised in place, so every
+    // epilogue that follows runs unchanged with bias = NULL (d carries it).
+    const float* lnb = (const float*)(smem + 8 * HALF_BYTES);
     f32x4 cq[4], dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = min(nbase + i * 16 + fq * 4, a.N - 4);
-      cq[i] = *(const f32x4*)(a.ln_c + eoff + n);
-      dq[i] = *(const f32x4*)(a.ln_d + eoff + n);
+      cq[i] = *(const f32x4*)(lnb + 512 + wc * 64 + i * 16 + fq * 4);
+      dq[i] = *(const f32x4*)(lnb + 768 + wc * 64 + i * 16 + fq * 4);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region, own writes
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const f32x2 st = *(const f32x2*)(mr + (j * 16 + fr) * 2);
+      const f32x2 st = *(const f32x2*)(lnb + (wr * 128 + j * 16 + fr) * 2);
       const float nm = -st[0] * st[1];                    // -mean rstd
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = st[1] * acc[i][j] + (nm * cq[i] + dq[i]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the statistics are read before the region is reused below
   }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
     if (a.N % 8 == 0 && a.ldo % 8 == 0) {
@@ -532,7 +518,7 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
   a.m_major = a.M > a.N;
-  constexpr int lds = 8 * HALF_BYTES;
+  constexpr int lds = 8 * HALF_BYTES + (FUSE == 1 ? 4096 : 0);
   static F5eDeviceOnce lds_once;  // 128 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
   F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG, FUSE>), lds);
   int n_cu = f5e_cu_count() / 8 * 8;
@@ -559,7 +545,8 @@ int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
   if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
   if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
   if (dbg == 6) return launch_pp_t<EPI_BF16_GELU, 6>(a, st);
-  if (a.ln_stats) {   // fused-AdaLN consumer (checked by the dispatcher: parts a multiple of 4 up to 16, one table row)
+  if (a.ln_stats) {   // fused-AdaLN consumer (checked by the dispatcher: one table row)
+    F5E_REQUIRE(a.ln_rowstats, "gemm_bf16_pp: the large-M AdaLN consumer needs f5e_ln_fuse.row_stats (f5e_ln_finalize)");
     switch (epi) {
       case EPI_BF16: return launch_pp_t<EPI_BF16, 0, 1>(a, st);
       case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU, 0, 1>(a, st);

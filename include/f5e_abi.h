@@ -83,7 +83,14 @@ typedef struct f5e_ln_fuse {
   const int* eval_ptr; int rows_per_seq; float eps;
   void* xs_out; int ld_xs; const float* next_scale;    /* producer (next_scale uses the gate's strides / rows) */
   float* stats_out;
+  const float* row_stats;                              /* consumer at LARGE M (the 256x256 kernel): [M + 1][2] = (mean, rstd)
+                                                          per row, made from `stats` by f5e_ln_finalize; NULL at small M */
 } f5e_ln_fuse;
+
+/* Large-M form of the consumer side: combines the `parts` tile statistics of every row once (Chan's formula, fixed order)
+ * into row_stats [rows + 1][2] = (mean, rsqrt(var + eps)) (one pad row: the 256x256 kernel fetches them in 16-byte pieces),
+ * so that the consumer GEMM's workgroups -- up to 12 per row block -- read 8 bytes per row instead of 8 * parts. */
+int f5e_ln_finalize(f5e_stream st, const float* stats, int parts, int D, float eps, int rows, float* row_stats);
 
 int f5e_gemm_bf16_bias_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                           int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln);
@@ -281,6 +288,7 @@ typedef struct f5e_dit_plan {
   float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
   const float* cd;                       /* [E][mod_rows][cd_stride] f32: per block c_qkv | d_qkv | c_ff1 | d_ff1 */
   int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
+  float* ln_rowstats;                    /* [S*N + 1][2] f32 workspace: finalized (mean, rstd) per row, large M only */
   /* batch-1 chains (fused AdaLN path): a few grid-tail workgroups of each block launch pull the weights of the launch after
    * next into the 256 MB Infinity Cache (the 646 MB of block weights cycle through it, so every GEMM otherwise streams
    * from HBM).  Pure performance hint: results never depend on it. */
@@ -293,7 +301,7 @@ typedef struct f5e_dit_plan {
  * need (ln_stats without fuse_ln, skip_* without w_skip) get size 0.  q, k and vt must be zero-filled once by the caller
  * (their pad rows are never written).  Host call, no kernel launch, no allocation. */
 enum { F5E_WS_H0 = 0, F5E_WS_H0_BF16, F5E_WS_C1, F5E_WS_X, F5E_WS_HN, F5E_WS_Q, F5E_WS_K, F5E_WS_VT, F5E_WS_AO, F5E_WS_FF,
-       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_COUNT };
+       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_LN_ROWSTATS, F5E_WS_COUNT };
 typedef struct f5e_dit_workspace {
   int n_pad;
   unsigned long long bytes[F5E_WS_COUNT];

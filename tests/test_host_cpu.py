@@ -56,7 +56,7 @@ def test_workspace_bytes_planner():
     assert w.n_pad == n_pad
     want = dict(h0=M * 1024 * 4, h0_bf16=M * 1024 * 2, c1=M * 1024 * 2, x=M * 1024 * 4, hn=M * 1024 * 2,
                 q=2 * 16 * n_pad * 64 * 2, k=2 * 16 * n_pad * 64 * 2, vt=2 * 16 * n_pad * 64 * 2, ao=M * 1024 * 2,
-                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0)
+                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0, ln_rowstats=0)
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got == want
     end = 0
@@ -68,6 +68,7 @@ def test_workspace_bytes_planner():
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == 0
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got["ln_stats"] == M * 16 * 2 * 4 and got["skip_res"] == got["skip_tmp"] == M * 1024 * 4
+    assert got["ln_rowstats"] == (M + 1) * 8
     p.N = 0
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == -1 and b"workspace_bytes" in lib.f5e_last_error()
 

@@ -498,7 +498,12 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     close(stats[:, :, 0], x.mean(1, keepdim=True).expand(M, P), 1e-5, 1e-6, "pre mean")
     close(stats[:, :, 1].sum(1), ((x - x.mean(1, keepdim=True)) ** 2).sum(1), 1e-5, 1e-4, "pre M2")
     out = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N), tile_hint=hint)
+    rows = torch.empty(M + 1, 2, device="cuda") if hint == 9 else None        # the 256x256 kernel reads finalized rows
+    if hint == 9:
+        ops.ln_finalize(stats, D, rows)
+        close(rows[:M, 0], x.mean(1), 1e-5, 1e-6, "finalized mean")
+        close(rows[:M, 1], torch.rsqrt(x.var(1, unbiased=False) + 1e-6), 1e-4, 1e-6, "finalized rstd")
+    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N, row_stats=rows), tile_hint=hint)
     hn = torch.empty(M, D, device="cuda", dtype=BF)
     ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:2 * D], rows_per_seq=N)
     unf = torch.empty(M, NO, device="cuda")
@@ -531,6 +536,8 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     close(st2[:, :, 0], tiles.mean(2), 1e-5, 1e-6, "producer tile mean")
     close(st2[:, :, 1], ((tiles - tiles.mean(2, keepdim=True)) ** 2).sum(2), 1e-4, 1e-4, "producer tile M2")
     out2 = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N), tile_hint=hint)
+    if hint == 9:
+        ops.ln_finalize(st2, D, rows)
+    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N, row_stats=rows), tile_hint=hint)
     ref2 = (F.layer_norm(xn, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
     assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) / float(ref2.std()) < 4e-3
