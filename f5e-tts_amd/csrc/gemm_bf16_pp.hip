@@ -127,10 +127,17 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
         wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
   };
 
+  // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
+#pragma unroll
+  for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
   if constexpr (FUSE == 1) {
     // fused-AdaLN consumer operands, fetched now and used in the epilogue: waves 0-1 the (mean, rstd) pairs of rows
-    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  They are
-    // the OLDEST vector-memory operations of their waves, so every counted wait of the main loop retires them first.
+    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  Issued
+    // BEHIND the prologue's half-tiles (in front of them a cold row_stats line delayed the first K-tile by a memory round
+    // trip per tile): one extra operation in the in-order vmcnt queue of waves 0-3.  vmcnt(6) then retires everything up to
+    // half-tile 3's first DMA in phase 0, half-tile 3 in phase 1, half-tile 4 and this operation in phase 2 -- each still
+    // at least one phase before its first read (h2: phase 1, h3: phase 2, h4: phase 4) -- and the window is the usual three
+    // half-tiles from phase 3 on.
     char* lnb = smem + 8 * HALF_BYTES;
     if (wave < 2) {
       const int r = min(m0 + wave * 128 + lane * 2, a.M - 1);
@@ -141,9 +148,6 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
       glds16((wave == 2 ? a.ln_c : a.ln_d) + eoff + n, lnb + 2048 + (wave - 2) * 1024);
     }
   }
-  // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
-#pragma unroll
-  for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
   wait_vm<6>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier (half a phase) behind group 0
@@ -217,18 +221,16 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     // the top of this tile (below): no memory round trip here.  The accumulators are normalised in place, so every
     // epilogue that follows runs unchanged with bias = NULL (d carries it).
     const float* lnb = (const float*)(smem + 8 * HALF_BYTES);
-    f32x4 cq[4], dq[4];
+    // column block outermost: only one (c, d) quad pair is live beside the 128 accumulator registers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      cq[i] = *(const f32x4*)(lnb + 512 + wc * 64 + i * 16 + fq * 4);
-      dq[i] = *(const f32x4*)(lnb + 768 + wc * 64 + i * 16 + fq * 4);
-    }
+      const f32x4 cq = *(const f32x4*)(lnb + 512 + wc * 64 + i * 16 + fq * 4);
+      const f32x4 dq = *(const f32x4*)(lnb + 768 + wc * 64 + i * 16 + fq * 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const f32x2 st = *(const f32x2*)(lnb + (wr * 128 + j * 16 + fr) * 2);
-      const float nm = -st[0] * st[1];                    // -mean rstd
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = st[1] * acc[i][j] + (nm * cq[i] + dq[i]);
+      for (int j = 0; j < 8; ++j) {
+        const f32x2 st = *(const f32x2*)(lnb + (wr * 128 + j * 16 + fr) * 2);
+        acc[i][j] = st[1] * acc[i][j] + ((-st[0] * st[1]) * cq + dq);
+      }
     }
   }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {

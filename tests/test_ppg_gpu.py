@@ -179,3 +179,77 @@ def test_ppg_feeds_sample_vc():
     out, _ = cfm.sample_vc(SY.synthetic_ref_wave(n_ref).cuda(), ppg, duration=n, steps=4, alpha_spk=2.5, alpha_ppg=3.0,
                            sway_sampling_coef=-1.0, seed=0)
     assert out.shape == (1, n, 100) and torch.isfinite(out).all()
+
+
+def test_eval_driver_vc_mode_extracts_ppg_on_the_gpu(tmp_path):
+    """BASELINE C5's real caller: eval_infer_batch.main(--mode vc) WITHOUT precomputed PPGs -- the wenet extractor runs on
+    the GPU on [prompt ; source] at 16 kHz (reference eval/utils_eval.py:281-336), the total length follows the source
+    utterance's duration (use_truth_duration), sample_vc + Vocos write the wav.  The written audio must equal a direct
+    extract -> sample_vc -> decode on the same inputs (int16 file round trip)."""
+    import yaml
+    from safetensors.torch import save_file
+
+    import f5e_tts_amd
+    from f5e_tts_amd.eval import eval_infer_batch as E
+    from f5e_tts_amd.infer import audio as A
+    from f5e_tts_amd.infer import utils_infer as U
+    from f5e_tts_amd.model import CFM, DiT
+    from f5e_tts_amd.ppg import ConformerPPG, PPGModelWapper
+    from f5e_tts_amd.train.parse_cfg import parse_model_yaml
+    from f5e_tts_amd.vocoder import Vocos
+    from tools import synth as SY
+    pkg = os.path.dirname(os.path.abspath(f5e_tts_amd.__file__))
+    cfg = yaml.safe_load(open(os.path.join(pkg, "configs", "F5TTS_Small_PPG.yaml")))
+    cfg["model"]["arch"].update(depth=2, conv_layers=2)
+    cfg["model"]["ppg_config"].update(model_path=str(tmp_path / "33.pt"), config=str(tmp_path / "train.yaml"))
+    (tmp_path / "model.yaml").write_text(yaml.safe_dump(cfg))
+    mc = parse_model_yaml(cfg)
+    torch.manual_seed(77)
+    dit = DiT(**mc["arch"], text_num_embeds=2545, mel_dim=100, ppg_config=mc["transformer_ppg_config"],
+              cb_config=mc["transformer_codebook_config"])
+    for p_ in dit.parameters():
+        if float(p_.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p_, std=0.02)
+    cfm = CFM(transformer=dit, ppg_config=mc["cfm_ppg_config"], cb_config=mc["cfm_codebook_config"])
+    save_file({"ema_model." + k: v.contiguous() for k, v in cfm.state_dict().items()}, str(tmp_path / "model.safetensors"))
+    cfm = cfm.cuda().eval()
+    ppg_cfg = dict(cmvn_file=None, is_json_cmvn=True, input_dim=80, output_dim=218, encoder="conformer",
+                   encoder_conf=dict(output_size=256, attention_heads=4, linear_units=512, num_blocks=2))
+    (tmp_path / "train.yaml").write_text(yaml.safe_dump(ppg_cfg))
+    pm = ConformerPPG.from_config(ppg_cfg)
+    torch.save(seeded_state(pm, 5), str(tmp_path / "33.pt"))
+    vdir = tmp_path / "vocos"
+    vdir.mkdir()
+    (vdir / "config.yaml").write_text(yaml.safe_dump({
+        "backbone": {"init_args": dict(input_channels=100, dim=512, intermediate_dim=1536, num_layers=8)},
+        "head": {"init_args": dict(dim=512, n_fft=1024, hop_length=256, padding="center")}}))
+    voc = Vocos()
+    voc.load_state_dict(SY.init_vocos_state(), strict=False)
+    torch.save(voc.state_dict(), str(vdir / "pytorch_model.bin"))
+    voc = voc.cuda().eval()
+    audio = tmp_path / "wavs"
+    audio.mkdir()
+    ref = SY.synthetic_ref_wave(96, seed=1)[0] * 3.0          # ~1 s prompt
+    src = SY.synthetic_ref_wave(190, seed=2)[0] * 3.0         # ~2 s source utterance
+    U.save_wav(str(audio / "ref0.wav"), ref.numpy(), 24000)
+    U.save_wav(str(audio / "gen0.wav"), src.numpy(), 24000)
+    (tmp_path / "test.lst").write_text("\t".join(["ref0", "1.0", "some prompt text.", "gen0", "2.0", "converted content."]) + "\n")
+    out_dir = tmp_path / "out"
+    E.main(["-n", "F5TTS_Small_PPG", "-t", str(tmp_path / "test.lst"), "-nfe", "4", "-s", "0", "--mode", "vc", "--ckpt",
+            str(tmp_path / "model.safetensors"), "--audio_root", str(audio), "--vocoder_path", str(vdir), "--output_dir",
+            str(out_dir), "-mc", str(tmp_path / "model.yaml")])
+    got, sr = U.load_wav(str(out_dir / "gen0.wav"))
+    a, _ = U.load_wav(str(audio / "ref0.wav"))
+    s, _ = U.load_wav(str(audio / "gen0.wav"))
+    ref_len = a.shape[-1] // 256
+    tot = ref_len + int(s.shape[-1] / 256)
+    assert sr == 24000 and got.shape == (1, 256 * (tot - ref_len - 1))
+    w = PPGModelWapper(str(tmp_path / "33.pt"), str(tmp_path / "train.yaml"), "cuda")
+    full16 = torch.cat([A.resample(a, 24000, 16000), A.resample(s, 24000, 16000)], dim=1)
+    ppg, _ = w.audio_to_ppg(full16.cuda(), 16000)
+    assert ppg.shape[2] == 256 and abs(ppg.shape[1] - round(0.533 * tot)) <= 3
+    mel_in = cfm.mel_spec(a.cuda()).permute(0, 2, 1)[:, :ref_len]
+    mel, _ = cfm.sample_vc(mel_in, ppg, duration=torch.tensor([tot]), steps=4, alpha_spk=2.5, alpha_ppg=3.0,
+                           sway_sampling_coef=-1.0, seed=0)
+    direct = voc.decode(mel[:, ref_len:tot].permute(0, 2, 1)).cpu()
+    assert float((got - direct.clamp(-1, 1)).abs().max()) <= 2.0 / 32768
