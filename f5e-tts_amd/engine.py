@@ -155,7 +155,11 @@ class DiTEngine:
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
         # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
         self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
-        self.fuse_ln_pp = os.environ.get("F5E_FUSE_LN_PP", "1") != "0"   # the large-M (ping-pong GEMM) form of the same
+        # The large-M (ping-pong GEMM) form of the same is built and tested but OFF by default: at C3 it trades the two
+        # LayerNorm launches of a block (2 x 60 us at the HBM roofline) for +82 us of GEMM epilogue (xs stores, in-place
+        # normalise, register pressure at 256 VGPRs) and three 5 us finalize launches -- break-even within run-to-run noise
+        # (24.8 k vs 24.9 k mel-frames/s, profiles/r02_f_*).  F5E_FUSE_LN_PP=1 switches it on.
+        self.fuse_ln_pp = os.environ.get("F5E_FUSE_LN_PP", "0") != "0"
         self.mall_prefetch = os.environ.get("F5E_MALL_PREFETCH", "1") != "0"  # Infinity-Cache weight prefetch at small M
         self._loops = threading.local()   # per-thread LRU of persistent loop states (see _LoopState)
         self._tables: Dict[tuple, Tensor] = {}
@@ -192,8 +196,8 @@ class DiTEngine:
 
     # Above this many rows per launch the 128x128 GEMM tiles win (QKV / FF1 at M = 3752: 41 / 23 us against 54 / 31 us for
     # the 64x64 tile the fusion needs, i.e. more than the two LayerNorm launches it saves): keep LayerNorm separate there.
-    # From 44 row tiles of 256 on (gemm_bf16.hip's crossover) the GEMMs run the 256x256 ping-pong kernel, which carries the
-    # fusion again: at C3 each LayerNorm launch is 369 MB of HBM traffic (60 us at the roofline), the fused form 123 MB.
+    # From 44 row tiles of 256 on (gemm_bf16.hip's crossover) the GEMMs run the 256x256 ping-pong kernel, which can carry the
+    # fusion too (opt-in, see fuse_ln_pp): at C3 each LayerNorm launch is 369 MB of HBM traffic, the fused form 123 MB.
     LN_FUSE_MAX_ROWS = 2800
     LN_FUSE_PP_MIN_ROWS = 43 * 256 + 1
 
