@@ -14,6 +14,7 @@
 //     The LDS image is lane-linear; the bank swizzle (16-B chunk ^ ((row>>1)&7)) is applied to the
 //     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
 //     16-lane ds_read_b128 groups are conflict free.
+#include <cstdlib>
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
 
@@ -40,9 +41,14 @@ __device__ __forceinline__ void wait_stages(int nst) {
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0>
+// BK = K-step: 64 (128-byte LDS rows, two rows per 256-byte bank line: swizzle (row >> 1) & 7) or 128 (256-byte rows = one
+// bank line each: swizzle row & 15).  A lone workgroup per CU (out-projection, FF2 at batch 1) pays a fixed ~600 cycles per
+// K-step whatever it moves (barrier -> DMA issue -> ds_read -> MFMA -> wait is one serial chain): BK = 128 halves the steps.
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
-  constexpr int BK = 64;
+  constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
+  constexpr int ROWB = BK * 2;                   // bytes per LDS row
+  auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (row & 15); };
   constexpr int NT = 64 * WGM * WGN;  // threads: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
@@ -95,24 +101,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- staging: chunk i (16 B) of a [rows][64] bf16 tile sits at LDS byte i*16 ----
-  // source chunk for LDS position (row, c) is c ^ ((row>>1)&7)
-  constexpr int A_IT = BM * 8 / NT;
-  constexpr int W_IT = BN * 8 / NT;
-  static_assert(A_IT >= 1 && W_IT >= 1 && A_IT * NT == BM * 8 && W_IT * NT == BN * 8, "tile / thread-count mismatch");
+  // ---- staging: chunk i (16 B) of a [rows][BK] bf16 tile sits at LDS byte i*16 ----
+  // source chunk for LDS position (row, c) is c ^ swz(row)
+  constexpr int A_IT = BM * CPR / NT;
+  constexpr int W_IT = BN * CPR / NT;
+  static_assert(A_IT >= 1 && W_IT >= 1 && A_IT * NT == BM * CPR && W_IT * NT == BN * CPR, "tile / thread-count mismatch");
+  static_assert(BK == 64 || BK == 128, "K-step 64 or 128");
   const bf16* a_src[A_IT];
   const bf16* w_src[W_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
     const int i = tid + NT * j;
-    const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+    const int row = i / CPR, c = (i % CPR) ^ swz(row);
     const int gr = min(m0 + row, a.M - 1);
     a_src[j] = a.A + (size_t)gr * a.lda + c * 8;
   }
 #pragma unroll
   for (int j = 0; j < W_IT; ++j) {
     const int i = tid + NT * j;
-    const int row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+    const int row = i / CPR, c = (i % CPR) ^ swz(row);
     const int gr = min(n0 + row, a.N - 1);
     w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
   }
@@ -235,18 +242,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     const char* As = smem + buf * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < (DBG == 1 ? 0 : 2); ++kk) {
+    for (int kk = 0; kk < (DBG == 1 ? 0 : BK / 32); ++kk) {
       bf16x8 xf[TM], wf[TN];
       const int c = kk * 4 + fq;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm0 + j * 16 + fr;
-        xf[j] = *(const bf16x8*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        xf[j] = *(const bf16x8*)(As + row * ROWB + ((c ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn0 + i * 16 + fr;
-        wf[i] = *(const bf16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        wf[i] = *(const bf16x8*)(Ws + row * ROWB + ((c ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int BK = 64>
 int launch(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -470,10 +477,10 @@ int launch(GemmArgs& a, hipStream_t st) {
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
   const int grid = a.n_main + ((WGM * WGN == 4 && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
   if (grid == a.n_main) a.pf = F5ePrefetch{};
-  constexpr int lds = NSTAGE * (BM + BN) * 64 * 2 + (FUSE ? 1024 : 0);
+  constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -504,6 +511,12 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, 0);
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
+      // one workgroup per CU (out-projection / FF2 at batch 1): K-step 128 halves the number of latency-bound steps
+      static const int bk128 = getenv("F5E_GEMM_BK128") ? atoi(getenv("F5E_GEMM_BK128")) : 0;   // A/B switch
+      if (bk128 && blocks(64, 64) <= 256 && a.K % 128 == 0) {
+        if (bk128 == 2) return launch<64, 64, EPI, 2, 2, 2, 0, 2, 128>(a, st);
+        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 128>(a, st);
+      }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {

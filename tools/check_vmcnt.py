@@ -82,7 +82,7 @@ def min_loads(ins, start, stop):
 
 bad = 0
 for key, ins in sorted(body.items()):
-    BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE = key
+    BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE = key[:8]   # a 9th parameter (K-step) does not change the counted loads
     TM, TN = BM // WGM // 16, BN // WGN // 16
     pref = TM * TN <= 4
     npc = 2 * TN + 4 if FUSE == 1 else 3 * TM * TN if FUSE == 2 else (2 * TM * TN if (pref and EPI == 2) else 0)
