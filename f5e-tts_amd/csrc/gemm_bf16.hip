@@ -42,8 +42,7 @@ __device__ __forceinline__ void wait_stages(int nst) {
 }
 
 // BK = K-step: 64 (128-byte LDS rows, two rows per 256-byte bank line: swizzle (row >> 1) & 7) or 128 (256-byte rows = one
-// bank line each: swizzle row & 15).  A lone workgroup per CU (out-projection, FF2 at batch 1) pays a fixed ~600 cycles per
-// K-step whatever it moves (barrier -> DMA issue -> ds_read -> MFMA -> wait is one serial chain): BK = 128 halves the steps.
+// bank line each: swizzle row & 15; kept as a tuning parameter, no shipped instantiation uses it -- see dispatch()).
 template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
@@ -511,12 +510,9 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, 0);
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
-      // one workgroup per CU (out-projection / FF2 at batch 1): K-step 128 halves the number of latency-bound steps
-      static const int bk128 = getenv("F5E_GEMM_BK128") ? atoi(getenv("F5E_GEMM_BK128")) : 0;   // A/B switch
-      if (bk128 && blocks(64, 64) <= 256 && a.K % 128 == 0) {
-        if (bk128 == 2) return launch<64, 64, EPI, 2, 2, 2, 0, 2, 128>(a, st);
-        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 128>(a, st);
-      }
+      // (K-step 128 -- template parameter BK -- was measured here for the one-workgroup-per-CU launches: out-projection /
+      // FF2 12.8 / 17.0 us with BK 64, 13.6 / 17.8 with BK 128 x 3 stages, 12.8 / 16.9 with BK 128 x 2 stages: the lone
+      // workgroup's K loop is bound by the ~65 GB/s a CU's LDS-DMA path delivers, not by the number of steps.)
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
