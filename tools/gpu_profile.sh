@@ -9,6 +9,7 @@ C2="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --steps 5 --warmup 2"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_c2 -o c2 -- python3 $R/bench.py $C2 > $R/gpurun_out/${tag}_prof_c2.json 2> $R/gpurun_out/${tag}_prof_c2.err || { echo "prof c2 failed"; tail -3 $R/gpurun_out/${tag}_prof_c2.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_c3 -o c3 -- python3 $R/bench.py --workload C3 --no-cpu-baseline --no-roofline --streams 0 --steps 2 --warmup 1 > $R/gpurun_out/${tag}_prof_c3.json 2> $R/gpurun_out/${tag}_prof_c3.err || { echo "prof c3 failed"; exit 1; }
+export F5E_LOOP_GRAPH=0   # counter collection crashes (SIGSEGV inside rocprofv3) on the 3700-node whole-loop graph: PMC passes replay the one-step graph
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- python3 $R/bench.py $C2 > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.err || { echo "pmc fetch failed"; tail -3 $R/gpurun_out/${tag}_pmc_fetch.err; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o w -- python3 $R/bench.py $C2 > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.err || { echo "pmc write failed"; exit 1; }
 cd $R
