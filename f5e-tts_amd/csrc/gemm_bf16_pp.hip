@@ -49,166 +49,14 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// FUSE: fused AdaLN at large M (same contract as gemm_bf16.hip, f5e_ln_fuse): 1 = consumer (A = xs, epilogue applies
-// rstd (acc - mean c[n]) + d[n] from the per-row tile statistics), 2 = producer (gate+residual epilogue also writes
-// xs = bf16(x_new (1 + next_scale)) and (mean, M2) of x_new per row and 64-column tile).
-template <int EPI, int DBG, int FUSE>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
-__device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+// Epilogue shared by the two tile schedules (pp_tile: 8 waves, 256 x 256; pp2_tile: 4 waves, 256 x 128).  A wave owns the
+// 128 x 64 sub-tile at rows m0 + 128 wr, columns n0 + 64 wc, accumulators acc[4][8] in the swapped-operand layout, and
+// 16 KiB of the (now idle) LDS ring at smem + wave * 16 KiB as staging space.  LNB = byte offset of the fused-AdaLN
+// consumer's operands behind the ring (FUSE == 1).
+template <int EPI, int DBG, int FUSE, int LNB>
+__device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4 (&acc)[4][8], int wave, int lane, int wr,
+                                            int wc, int m0, int n0) {
   const int fr = lane & 15, fq = lane >> 4;
-
-  // XCD-aware tile order (same bijection as gemm_bf16.hip): blocks sharing blockIdx % 8 walk neighbouring tiles
-  int bid = phys_id;
-  {
-    const int nblk = n_tiles;
-    const int q8 = nblk >> 3, r8 = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  int tile_m, tile_n;
-  if (a.m_major) {
-    tile_m = bid / a.tiles_n;
-    tile_n = bid - tile_m * a.tiles_n;
-  } else {
-    tile_n = bid / a.tiles_m;
-    tile_m = bid - tile_n * a.tiles_m;
-  }
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-
-  // DMA sources: thread tid moves chunks i = tid and tid + 512 of every half-tile; slot row r = i >> 3 holds, at
-  // physical chunk i & 7, the logical chunk (i & 7) ^ ((r >> 1) & 7) of the source row
-  const bf16* src[4][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int i = tid + 512 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
-    const int xa = m0 + (r >> 6) * 128 + (r & 63), wa = n0 + (r >> 5) * 64 + (r & 31);
-    src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
-    src[1][j] = a.W + (size_t)min(wa, a.N - 1) * a.ldw + c * 8;       // WH0
-    src[2][j] = a.W + (size_t)min(wa + 32, a.N - 1) * a.ldw + c * 8;  // WH1
-    src[3][j] = a.A + (size_t)min(xa + 64, a.M - 1) * a.lda + c * 8;  // XHb
-  }
-  const int KT = a.K / 64, TI = 4 * KT;
-  auto stage = [&](int idx) {
-    const int kt = idx >> 2, type = idx & 3;
-    char* dst = smem + (((kt & 1) << 2) + type) * HALF_BYTES + wave * 1024;
-    const bf16* s0 = type == 0 ? src[0][0] : (type == 1 ? src[1][0] : (type == 2 ? src[2][0] : src[3][0]));
-    const bf16* s1 = type == 0 ? src[0][1] : (type == 1 ? src[1][1] : (type == 2 ? src[2][1] : src[3][1]));
-    glds16(s0 + kt * 64, dst);
-    glds16(s1 + kt * 64, dst + 512 * 16);
-  };
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addresses inside a slot: row * 128 + ((c ^ sw) << 4), c = kk * 4 + fq, sw = (fr >> 1) & 7
-  const int sw = (fr >> 1) & 7;
-  const int xoff = (wr * 64 + fr) * 128, woff = (wc * 32 + fr) * 128;
-  bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
-  auto read_x = [&](const char* slot) {
-    if (DBG == 2 || DBG == 4) return;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
-  };
-  auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
-    if (DBG == 2 || DBG == 4) return;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
-  };
-
-  // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
-#pragma unroll
-  for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
-  if constexpr (FUSE == 1) {
-    // fused-AdaLN consumer operands, fetched now and used in the epilogue: waves 0-1 the (mean, rstd) pairs of rows
-    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  Issued
-    // BEHIND the prologue's half-tiles (in front of them a cold row_stats line delayed the first K-tile by a memory round
-    // trip per tile): one extra operation in the in-order vmcnt queue of waves 0-3.  vmcnt(6) then retires everything up to
-    // half-tile 3's first DMA in phase 0, half-tile 3 in phase 1, half-tile 4 and this operation in phase 2 -- each still
-    // at least one phase before its first read (h2: phase 1, h3: phase 2, h4: phase 4) -- and the window is the usual three
-    // half-tiles from phase 3 on.
-    char* lnb = smem + 8 * HALF_BYTES;
-    if (wave < 2) {
-      const int r = min(m0 + wave * 128 + lane * 2, a.M - 1);
-      glds16(a.ln_rowstats + (size_t)r * 2, lnb + wave * 1024);
-    } else if (wave < 4) {
-      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
-      const int n = min(n0 + lane * 4, a.N - 4);
-      glds16((wave == 2 ? a.ln_c : a.ln_d) + eoff + n, lnb + 2048 + (wave - 2) * 1024);
-    }
-  }
-  wait_vm<6>();
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier (half a phase) behind group 0
-
-  auto phase_tail = [&](int p) {  // stage half-tile p + 5, then leave only the 3 youngest half-tiles in flight
-    const int idx = p + 5;
-    if (DBG == 1 || DBG == 4) return;
-    if (idx < TI) stage(idx);
-    const int rem = TI - 1 - idx;  // half-tiles still to be staged after this phase
-    if (rem >= 0) wait_vm<6>();
-    else if (rem == -1) wait_vm<4>();
-    else if (rem == -2) wait_vm<2>();
-    else wait_vm<0>();
-  };
-  auto mfma_quadrant = [&](auto qa_c, auto qb_c, bf16x8 (&wf)[2][2]) {
-    constexpr int qa = decltype(qa_c)::value, qb = decltype(qb_c)::value;  // compile-time accumulator indices
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < ((DBG == 3 || DBG == 4) ? 0 : 2); ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[qb * 2 + i][qa * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[qb * 2 + i][qa * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-  };
-
-  for (int kt = 0; kt < KT; ++kt) {
-    const char* buf = smem + ((kt & 1) << 2) * HALF_BYTES;
-    const int p = kt * 4;
-    // phase 0: (A0, B0)
-    read_x(buf);
-    read_w(buf + HALF_BYTES, wf0);
-    phase_tail(p);
-    mfma_quadrant(I0{}, I0{}, wf0);
-    // phase 1: (A0, B1)
-    read_w(buf + 2 * HALF_BYTES, wf1);
-    phase_tail(p + 1);
-    mfma_quadrant(I0{}, I1{}, wf1);
-    // phase 2: (A1, B1)
-    read_x(buf + 3 * HALF_BYTES);
-    phase_tail(p + 2);
-    mfma_quadrant(I1{}, I1{}, wf1);
-    // phase 3: (A1, B0), operands already in registers
-    phase_tail(p + 3);
-    mfma_quadrant(I1{}, I0{}, wf0);
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
-
-  if (DBG == 5) {  // no epilogue: keep the accumulators alive with a store that never happens
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (s == 1.2345e33f) ((float*)a.out)[tid] = s;
-    return;
-  }
   // ---- epilogue.  With one workgroup per CU nothing hides it, and the MFMA accumulator layout stores 8 B (bf16) or 16 B
   // (fp32) pieces of 16 different rows per instruction: the memory system sees partial lines (measured: 22 us per
   // workgroup for 128 KiB of bf16 output).  So the wave's 128 x 64 sub-tile goes through its 16 KiB share of the now
@@ -220,7 +68,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     // (mean, rstd) of the tile's 256 rows and c / d of its 256 columns were LDS-DMA'd into the 4 KiB behind the ring at
     // the top of this tile (below): no memory round trip here.  The accumulators are normalised in place, so every
     // epilogue that follows runs unchanged with bias = NULL (d carries it).
-    const float* lnb = (const float*)(smem + 8 * HALF_BYTES);
+    const float* lnb = (const float*)(smem + LNB);
     // column block outermost: only one (c, d) quad pair is live beside the 128 accumulator registers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -485,6 +333,169 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   gemm_epilogue<EPI, 8, 4>(a, acc, mbase, nbase, lane);
 }
 
+// FUSE: fused AdaLN at large M (same contract as gemm_bf16.hip, f5e_ln_fuse): 1 = consumer (A = xs, epilogue applies
+// rstd (acc - mean c[n]) + d[n] from the per-row tile statistics), 2 = producer (gate+residual epilogue also writes
+// xs = bf16(x_new (1 + next_scale)) and (mean, M2) of x_new per row and 64-column tile).
+template <int EPI, int DBG, int FUSE>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
+__device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware tile order (same bijection as gemm_bf16.hip): blocks sharing blockIdx % 8 walk neighbouring tiles
+  int bid = phys_id;
+  {
+    const int nblk = n_tiles;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  int tile_m, tile_n;
+  if (a.m_major) {
+    tile_m = bid / a.tiles_n;
+    tile_n = bid - tile_m * a.tiles_n;
+  } else {
+    tile_n = bid / a.tiles_m;
+    tile_m = bid - tile_n * a.tiles_m;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // DMA sources: thread tid moves chunks i = tid and tid + 512 of every half-tile; slot row r = i >> 3 holds, at
+  // physical chunk i & 7, the logical chunk (i & 7) ^ ((r >> 1) & 7) of the source row
+  const bf16* src[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 512 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
+    const int xa = m0 + (r >> 6) * 128 + (r & 63), wa = n0 + (r >> 5) * 64 + (r & 31);
+    src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
+    src[1][j] = a.W + (size_t)min(wa, a.N - 1) * a.ldw + c * 8;       // WH0
+    src[2][j] = a.W + (size_t)min(wa + 32, a.N - 1) * a.ldw + c * 8;  // WH1
+    src[3][j] = a.A + (size_t)min(xa + 64, a.M - 1) * a.lda + c * 8;  // XHb
+  }
+  const int KT = a.K / 64, TI = 4 * KT;
+  auto stage = [&](int idx) {
+    const int kt = idx >> 2, type = idx & 3;
+    char* dst = smem + (((kt & 1) << 2) + type) * HALF_BYTES + wave * 1024;
+    const bf16* s0 = type == 0 ? src[0][0] : (type == 1 ? src[1][0] : (type == 2 ? src[2][0] : src[3][0]));
+    const bf16* s1 = type == 0 ? src[0][1] : (type == 1 ? src[1][1] : (type == 2 ? src[2][1] : src[3][1]));
+    glds16(s0 + kt * 64, dst);
+    glds16(s1 + kt * 64, dst + 512 * 16);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a slot: row * 128 + ((c ^ sw) << 4), c = kk * 4 + fq, sw = (fr >> 1) & 7
+  const int sw = (fr >> 1) & 7;
+  const int xoff = (wr * 64 + fr) * 128, woff = (wc * 32 + fr) * 128;
+  bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
+  auto read_x = [&](const char* slot) {
+    if (DBG == 2 || DBG == 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+  auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
+    if (DBG == 2 || DBG == 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+
+  // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
+#pragma unroll
+  for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
+  if constexpr (FUSE == 1) {
+    // fused-AdaLN consumer operands, fetched now and used in the epilogue: waves 0-1 the (mean, rstd) pairs of rows
+    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  Issued
+    // BEHIND the prologue's half-tiles (in front of them a cold row_stats line delayed the first K-tile by a memory round
+    // trip per tile): one extra operation in the in-order vmcnt queue of waves 0-3.  vmcnt(6) then retires everything up to
+    // half-tile 3's first DMA in phase 0, half-tile 3 in phase 1, half-tile 4 and this operation in phase 2 -- each still
+    // at least one phase before its first read (h2: phase 1, h3: phase 2, h4: phase 4) -- and the window is the usual three
+    // half-tiles from phase 3 on.
+    char* lnb = smem + 8 * HALF_BYTES;
+    if (wave < 2) {
+      const int r = min(m0 + wave * 128 + lane * 2, a.M - 1);
+      glds16(a.ln_rowstats + (size_t)r * 2, lnb + wave * 1024);
+    } else if (wave < 4) {
+      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+      const int n = min(n0 + lane * 4, a.N - 4);
+      glds16((wave == 2 ? a.ln_c : a.ln_d) + eoff + n, lnb + 2048 + (wave - 2) * 1024);
+    }
+  }
+  wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier (half a phase) behind group 0
+
+  auto phase_tail = [&](int p) {  // stage half-tile p + 5, then leave only the 3 youngest half-tiles in flight
+    const int idx = p + 5;
+    if (DBG == 1 || DBG == 4) return;
+    if (idx < TI) stage(idx);
+    const int rem = TI - 1 - idx;  // half-tiles still to be staged after this phase
+    if (rem >= 0) wait_vm<6>();
+    else if (rem == -1) wait_vm<4>();
+    else if (rem == -2) wait_vm<2>();
+    else wait_vm<0>();
+  };
+  auto mfma_quadrant = [&](auto qa_c, auto qb_c, bf16x8 (&wf)[2][2]) {
+    constexpr int qa = decltype(qa_c)::value, qb = decltype(qb_c)::value;  // compile-time accumulator indices
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < ((DBG == 3 || DBG == 4) ? 0 : 2); ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[qb * 2 + i][qa * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[qb * 2 + i][qa * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* buf = smem + ((kt & 1) << 2) * HALF_BYTES;
+    const int p = kt * 4;
+    // phase 0: (A0, B0)
+    read_x(buf);
+    read_w(buf + HALF_BYTES, wf0);
+    phase_tail(p);
+    mfma_quadrant(I0{}, I0{}, wf0);
+    // phase 1: (A0, B1)
+    read_w(buf + 2 * HALF_BYTES, wf1);
+    phase_tail(p + 1);
+    mfma_quadrant(I0{}, I1{}, wf1);
+    // phase 2: (A1, B1)
+    read_x(buf + 3 * HALF_BYTES);
+    phase_tail(p + 2);
+    mfma_quadrant(I1{}, I1{}, wf1);
+    // phase 3: (A1, B0), operands already in registers
+    phase_tail(p + 3);
+    mfma_quadrant(I1{}, I0{}, wf0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+
+  if (DBG == 5) {  // no epilogue: keep the accumulators alive with a store that never happens
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 1.2345e33f) ((float*)a.out)[tid] = s;
+    return;
+  }
+  pp_epilogue<EPI, DBG, FUSE, 8 * HALF_BYTES>(a, smem, acc, wave, lane, wr, wc, m0, n0);
+}
+
 // Persistent launch: one workgroup per CU walks tiles phys_id = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of
 // 8, so a workgroup keeps its XCD class and the XCD-aware order of pp_tile is unchanged).  Two reasons.  (1) With 128 KiB
 // of LDS only one workgroup fits a CU, so nothing overlaps a workgroup's exit (store acknowledgement) and its
@@ -515,6 +526,194 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second schedule ("pp2"): 4 waves, 256 x 128 tile, 80 KiB of LDS -> TWO workgroups per CU.
+//
+// Why: with one 8-wave workgroup per CU nothing overlaps a tile's epilogue (22-30 % of the GEMM time at C3: the stores
+// run at the HBM roofline while the matrix pipe idles) and the accumulators fill the register file, so the epilogue
+// cannot be software-pipelined into the next tile's K loop.  Two independent workgroups per CU get that overlap from the
+// hardware: each SIMD hosts one wave of each, the matrix pipe serves whichever has MFMAs, and one workgroup's epilogue
+// runs beside the other's K loop (the second half of the grid starts half a tile late).  The price is 1.5x the LDS fill
+// per flop (a 256 x 128 tile loads 48 KiB per K-tile for half the outputs of 64 KiB).
+//
+// Geometry.  wave = wr * 2 + wc owns rows [128 wr, +128) x columns [64 wc, +64): the same 128 x 64 wave tile, fragment
+// reads and quadrant order (A0,B0), (A0,B1), (A1,B1), (A1,B0) as pp_tile.  A K-tile is THREE 16 KiB pieces:
+//     XHa: rows {0..63} of both row halves   W: all 128 columns (per wc: B0 = 32 rows, then B1)   XHb: rows {64..127}
+// in a ring of FIVE slots, piece h = 3 kt + type in slot h % 5 (pieces are issued in increasing h).
+//
+// Schedule (ONE barrier per phase; a wave finishes its own LDS reads -- lgkmcnt(0) -- before the barrier):
+//     phase (t,0): read XHa_t, W_t[B0]; issue W_{t+1}                      [slot of XHb_{t-1}: last read (t-1,2)]
+//     phase (t,1): read W_t[B1];        wait until XHb_t has landed          (keeps XHa_{t+1}, W_{t+1} in flight: vmcnt(8))
+//     phase (t,2): read XHb_t;          issue XHb_{t+1}                     [slot of XHa_t: last read (t,0)]
+//     phase (t,3): no read;             issue XHa_{t+2}; wait until XHa_{t+1}, W_{t+1} have landed (keeps the two youngest)
+//                                                                            [slot of W_t: last read (t,1)]
+//   RAW: every piece is read at the earliest one phase after the wait (by every wave, followed by the barrier) that
+//        retires it.  WAR: a slot is re-staged at the earliest in the phase after the one whose barrier followed its last
+//        read.  The waits shrink at the end of K as pieces stop being issued.
+template <int EPI>
+__device__ __forceinline__ void pp2_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
+  constexpr int PIECE = 16384;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  int bid = phys_id;
+  {
+    const int nblk = n_tiles;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  int tile_m, tile_n;
+  if (a.m_major) {
+    tile_m = bid / a.tiles_n;
+    tile_n = bid - tile_m * a.tiles_n;
+  } else {
+    tile_n = bid / a.tiles_m;
+    tile_m = bid - tile_n * a.tiles_m;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+
+  // DMA sources: thread tid moves chunks i = tid + 256 j (j < 4) of every piece; LDS row r = i >> 3 holds, at physical
+  // chunk i & 7, the logical chunk (i & 7) ^ ((r >> 1) & 7) of its source row
+  const bf16* src[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
+    const int xa = m0 + (r >> 6) * 128 + (r & 63);
+    const int wn = n0 + (r >> 6) * 64 + ((r >> 5) & 1) * 32 + (r & 31);
+    src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
+    src[1][j] = a.W + (size_t)min(wn, a.N - 1) * a.ldw + c * 8;       // W
+    src[2][j] = a.A + (size_t)min(xa + 64, a.M - 1) * a.lda + c * 8;  // XHb
+  }
+  const int KT = a.K / 64;
+  int islot = 0;  // slot of the next piece to issue
+  auto issue = [&](int type, int kt) {
+    char* dst = smem + islot * PIECE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16* sp = type == 0 ? src[0][j] : (type == 1 ? src[1][j] : src[2][j]);
+      glds16(sp + kt * 64, dst + j * 4096);
+    }
+    islot = islot == 4 ? 0 : islot + 1;
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = (fr >> 1) & 7;
+  const int xoff = (wr * 64 + fr) * 128, woff = (wc * 64 + fr) * 128;
+  bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
+  auto read_x = [&](const char* slot) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+  auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
+  };
+  auto mfma_quadrant = [&](auto qa_c, auto qb_c, bf16x8 (&wf)[2][2]) {
+    constexpr int qa = decltype(qa_c)::value, qb = decltype(qb_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads done BEFORE the barrier: the slot may be re-staged after it
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[qb * 2 + i][qa * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[qb * 2 + i][qa * 4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_keep = [&](int pieces) {   // all but the `pieces` youngest pieces (4 DMAs each) of this wave have landed
+    if (pieces >= 2) wait_vm<8>();
+    else if (pieces == 1) wait_vm<4>();
+    else wait_vm<0>();
+  };
+
+  // prologue: XHa_0, W_0, XHb_0, XHa_1 (dispatch guarantees KT >= 2); the first two must have landed before phase (0,0)
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(0, 1);
+  wait_vm<8>();
+  __builtin_amdgcn_s_barrier();
+
+  int rs = 0;  // slot of XHa_kt; W_kt and XHb_kt follow
+  for (int kt = 0; kt < KT; ++kt) {
+    const int s1 = rs + 1 >= 5 ? rs - 4 : rs + 1, s2 = rs + 2 >= 5 ? rs - 3 : rs + 2;
+    const char* X = smem + rs * PIECE;
+    const char* Wp = smem + s1 * PIECE;
+    const char* Xb = smem + s2 * PIECE;
+    const bool n1 = kt + 1 < KT, n2 = kt + 2 < KT;
+    // phase 0: (A0, B0)
+    read_x(X);
+    read_w(Wp, wf0);
+    if (n1) issue(1, kt + 1);
+    mfma_quadrant(I0{}, I0{}, wf0);
+    // phase 1: (A0, B1)
+    read_w(Wp + 32 * 128, wf1);
+    wait_keep(n1 ? 2 : 0);
+    mfma_quadrant(I0{}, I1{}, wf1);
+    // phase 2: (A1, B1)
+    read_x(Xb);
+    if (n1) issue(2, kt + 1);
+    mfma_quadrant(I1{}, I1{}, wf1);
+    // phase 3: (A1, B0), operands already in registers
+    if (n2) issue(0, kt + 2);
+    wait_keep((n1 ? 1 : 0) + (n2 ? 1 : 0));
+    mfma_quadrant(I1{}, I0{}, wf0);
+    rs = rs + 3 >= 5 ? rs - 2 : rs + 3;
+  }
+  // every wave is past its last LDS read (phase (KT-1,2), before that phase's barrier): the ring is free for the epilogue
+  pp_epilogue<EPI, 0, 0, 0>(a, smem, acc, wave, lane, wr, wc, m0, n0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_pp2_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
+  // two workgroups share a CU: the second half of the grid starts half a tile late, so that one's epilogue falls into the
+  // other's K loop from the first tile on (~2200 cycles per K-tile measured; s_sleep 127 = 8128 cycles)
+  if (a.pp_stagger && (int)blockIdx.x >= grid / 2) {
+    const int naps = (int)((long long)(a.K / 64) * 1100 / 8128);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  for (int p = blockIdx.x; p < n_tiles; p += grid) {
+    pp2_tile<EPI>(a, smem, p, n_tiles);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <int EPI>
+int launch_pp2_t(GemmArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 127) / 128;
+  a.m_major = a.M > a.N;
+  constexpr int lds = 5 * 16384;
+  static F5eDeviceOnce lds_once;
+  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp2_kernel<EPI>), lds);
+  int n_cu = f5e_cu_count() / 8 * 8;
+  if (n_cu == 0) n_cu = 8;
+  const char* se = getenv("F5E_PP_STAGGER");
+  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
+  const int n_tiles = a.tiles_m * a.tiles_n;
+  const int grid = n_tiles < 2 * n_cu ? (n_tiles + 7) / 8 * 8 : 2 * n_cu;
+  hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI>), dim3(grid), dim3(256), lds, st, a);
+  F5E_LAUNCH_CHECK("gemm_bf16_pp2");
+  return F5E_OK;
+}
+
 template <int EPI, int DBG = 0, int FUSE = 0>
 int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
@@ -541,6 +740,17 @@ namespace f5e_gemm {
 
 int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
   F5E_REQUIRE(a.K % 64 == 0 && a.K >= 128, "gemm_bf16_pp: K=%d must be a multiple of 64 and >= 128", a.K);
+  static const int pp2_env = getenv("F5E_PP2") ? atoi(getenv("F5E_PP2")) : 0;
+  if ((dbg == 8 || (dbg == 0 && pp2_env)) && !a.ln_stats && !a.stats_out) {
+    switch (epi) {
+      case EPI_BF16: return launch_pp2_t<EPI_BF16>(a, st);
+      case EPI_BF16_GELU: return launch_pp2_t<EPI_BF16_GELU>(a, st);
+      case EPI_GATE_RES: return launch_pp2_t<EPI_GATE_RES>(a, st);
+      case EPI_QKV_ROPE: return launch_pp2_t<EPI_QKV_ROPE>(a, st);
+      case EPI_F32: return launch_pp2_t<EPI_F32>(a, st);
+    }
+  }
+  if (dbg == 8) dbg = 0;
   if (dbg == 1) return launch_pp_t<EPI_BF16_GELU, 1>(a, st);
   if (dbg == 2) return launch_pp_t<EPI_BF16_GELU, 2>(a, st);
   if (dbg == 3) return launch_pp_t<EPI_BF16_GELU, 3>(a, st);
