@@ -108,9 +108,65 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
         const int m = mbase + r, n = nbase + c * 8;
         const uint4 v = *(const uint4*)(reg + r * 128 + ((c ^ (r & 7)) << 4));
         if (DBG == 6) { if (v.x == 0x7fc1u && m < 0) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v; }  // no stores
-        else if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v;
+        else if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)(DBG == 10 ? (m & 4095) : m) * a.ldo + n) = v;
       }
       return;
+    }
+  }
+  if constexpr (EPI == EPI_GATE_RES && FUSE == 0) {
+    // Lean read-modify-write for the common wave tile: all 128 rows inside [0, M) and inside their sequences' lengths, one
+    // gate row.  Sequence, position, lengths and gate row are per-wave scalars (the wave's rows touch at most two sequences
+    // when rows_per_seq >= 128), so the per-row division / modulo / loop / predicate of the general path below (~3000
+    // instructions per wave; 16 us per tile at C3 = a third of the out-projection) disappears, and all 16 residual loads of
+    // a 64-row half are in flight together: two memory round trips per tile instead of four.  (Both halves at once = 128
+    // VGPRs of loads beside the 64 live accumulators: spills, 55 us per tile; half 1's loads issued row by row behind half
+    // 0's stores: no gain, the tile's 512 KiB of read-modify-write are then at the memory system's rate.)  The LDS pass itself stays: from the
+    // accumulator layout a store instruction would touch 16 rows x 64 B, which the memory system serves at half the rate of
+    // whole 256-byte row segments (measured: 24 us per tile without the LDS pass).
+    if (a.N % 4 == 0 && a.rows_per_seq >= 128 && nbase + 64 <= a.N && mbase + 128 <= a.M) {
+      const int seq = div_magic(mbase, a.rows_per_seq, a.rps_magic);
+      const int pos0 = mbase - seq * a.rows_per_seq;
+      const int rb = min(128, a.rows_per_seq - pos0);  // rows [0, rb): sequence seq, [rb, 128): sequence seq + 1
+      const int len_a = a.seq_len ? load_uniform_i32(a.seq_len + seq) : a.rows_per_seq;
+      const int len_b = (rb < 128 && a.seq_len) ? load_uniform_i32(a.seq_len + seq + 1) : a.rows_per_seq;
+      const int grow_a = seq % a.gate_rows, grow_b = (seq + 1) % a.gate_rows;
+      if (len_a - pos0 >= rb && len_b >= 128 - rb && (rb == 128 || grow_b == grow_a)) {  // uniform
+        const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
+        const int c = lane & 15, rq = lane >> 4;
+        const f32x4 ga = *(const f32x4*)(a.gate + eoff + (size_t)grow_a * a.gate_stride + nbase + c * 4);
+        const f32x4 bc = a.bias ? *(const f32x4*)(a.bias + nbase + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // uniform base + 32-bit byte offset per row (a 128-row tile of fp32 spans < 2^31 bytes).  The row stride is made
+        // opaque per tile: otherwise the row offsets are hoisted out of the persistent tile loop as loop invariants, live
+        // (and spilled) across the K loop
+        int ldr = a.ldr;
+        asm volatile("" : "+s"(ldr));
+        char* const xbase = (char*)(a.resid + (size_t)mbase * ldr + nbase);
+        const unsigned rstride = (unsigned)ldr * 4u, off0 = (unsigned)rq * rstride + (unsigned)c * 16u;
+        // LDS: 64 rows x 256 B, the 16-byte chunk index XORed with row & 15.  Read side: row = 4 b + rq, so the address is
+        // (rq * 256 + ((c ^ rq) << 4)) ^ ((b & 3) << 6) plus the constant 1024 b: four distinct registers
+        const int rd0 = rq * 256 + ((c ^ rq) << 4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int r = jj * 16 + fr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              *(f32x4*)(reg + r * 256 + (((i * 4 + fq) ^ (r & 15)) << 4)) = acc[i][half * 4 + jj];
+          }
+          f32x4 xv[16];
+#pragma unroll
+          for (int b = 0; b < 16; ++b) xv[b] = *(const f32x4*)(xbase + (off0 + (unsigned)(half * 64 + b * 4) * rstride));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int b = 0; b < 16; ++b) {
+            const f32x4 v = *(const f32x4*)(reg + ((rd0 ^ ((b & 3) << 6)) + b * 1024));
+            *(f32x4*)(xbase + (off0 + (unsigned)(half * 64 + b * 4) * rstride)) = xv[b] + ga * (v + bc);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the region is overwritten
+        }
+        return;
+      }
     }
   }
   if constexpr (EPI == EPI_GATE_RES) {
@@ -337,8 +393,18 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
 // rstd (acc - mean c[n]) + d[n] from the per-row tile statistics), 2 = producer (gate+residual epilogue also writes
 // xs = bf16(x_new (1 + next_scale)) and (mean, M2) of x_new per row and 64-column tile).
 template <int EPI, int DBG, int FUSE>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
-__device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
+__device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles, int iter = 0) {
   const int tid = threadIdx.x;
+  // DBG 7 (tools build, tools/pp_timeline.py): wall-clock stamps (100 MHz) per workgroup and tile: entry, first K-tile
+  // landed (includes the previous tile's store acknowledgements: vmcnt is in order), K loop done, epilogue issued
+  auto stamp = [&](int k) {
+    if (DBG >= 7 && tid == 0 && a.trace && iter < 16)
+      a.trace[((size_t)blockIdx.x * 16 + iter) * 4 + k] = __builtin_amdgcn_s_memrealtime();
+    // shader-clock copies of stamps 1 and 2 behind the table: effective core clock inside the K loop
+    if (DBG >= 7 && tid == 0 && a.trace && iter < 16 && (k == 1 || k == 2))
+      a.trace[(size_t)gridDim.x * 64 + ((size_t)blockIdx.x * 16 + iter) * 2 + (k - 1)] = __builtin_readcyclecounter();
+  };
+  stamp(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -368,7 +434,9 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int i = tid + 512 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
-    const int xa = m0 + (r >> 6) * 128 + (r & 63), wa = n0 + (r >> 5) * 64 + (r & 31);
+    int xa = m0 + (r >> 6) * 128 + (r & 63);
+    const int wa = n0 + (r >> 5) * 64 + (r & 31);
+    if (DBG == 9 || DBG == 10) xa &= 4095;  // timing experiment: the A operand from a cache-resident window
     src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
     src[1][j] = a.W + (size_t)min(wa, a.N - 1) * a.ldw + c * 8;       // WH0
     src[2][j] = a.W + (size_t)min(wa + 32, a.N - 1) * a.ldw + c * 8;  // WH1
@@ -434,6 +502,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   }
   wait_vm<6>();
   __builtin_amdgcn_s_barrier();
+  stamp(1);
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier (half a phase) behind group 0
 
   auto phase_tail = [&](int p) {  // stage half-tile p + 5, then leave only the 3 youngest half-tiles in flight
@@ -483,6 +552,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     mfma_quadrant(I1{}, I0{}, wf0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+  stamp(2);
 
   if (DBG == 5) {  // no epilogue: keep the accumulators alive with a store that never happens
     float s = 0.f;
@@ -494,6 +564,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     return;
   }
   pp_epilogue<EPI, DBG, FUSE, 8 * HALF_BYTES>(a, smem, acc, wave, lane, wr, wc, m0, n0);
+  stamp(3);
 }
 
 // Persistent launch: one workgroup per CU walks tiles phys_id = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of
@@ -519,8 +590,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
     const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  for (int p = blockIdx.x; p < n_tiles; p += grid) {
-    pp_tile<EPI, DBG, FUSE>(a, smem, p, n_tiles);
+  int iter = 0;
+  for (int p = blockIdx.x; p < n_tiles; p += grid, ++iter) {
+    pp_tile<EPI, DBG, FUSE>(a, smem, p, n_tiles, iter);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
     __builtin_amdgcn_s_barrier();
   }
@@ -719,6 +791,7 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
   a.m_major = a.M > a.N;
+  a.rps_magic = div_magic_of(a.rows_per_seq);
   constexpr int lds = 8 * HALF_BYTES + (FUSE == 1 ? 4096 : 0);
   static F5eDeviceOnce lds_once;  // 128 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
   F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG, FUSE>), lds);
@@ -727,6 +800,9 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
   a.pp_stagger = (se && se[0] == '0') ? 0 : ((se && se[0] == '2') ? 2 : 1);
   const int n_tiles = a.tiles_m * a.tiles_n;
+#ifdef F5E_TOOLS
+  if (DBG >= 7) a.trace = getenv("F5E_PP_TRACE") ? (unsigned long long*)strtoull(getenv("F5E_PP_TRACE"), nullptr, 0) : nullptr;
+#endif
   const char* pe = getenv("F5E_PP_PERSIST");  // read every launch: A/B switch for tuning runs
   const int grid = (pe && pe[0] == '0') ? n_tiles : (n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu);
   hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG, FUSE>), dim3(grid), dim3(512), lds, st, a);
@@ -757,6 +833,17 @@ int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
   if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
   if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
   if (dbg == 6) return launch_pp_t<EPI_BF16_GELU, 6>(a, st);
+#ifdef F5E_TOOLS
+  if (dbg == 9) return launch_pp_t<EPI_BF16_GELU, 9>(a, st);
+  if (dbg == 10) return launch_pp_t<EPI_BF16_GELU, 10>(a, st);
+  if (dbg == 7) {
+    switch (epi) {
+      case EPI_GATE_RES: return launch_pp_t<EPI_GATE_RES, 7>(a, st);
+      case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 7>(a, st);
+      default: return launch_pp_t<EPI_BF16_GELU, 7>(a, st);
+    }
+  }
+#endif
   if (a.ln_stats) {   // fused-AdaLN consumer (checked by the dispatcher: one table row)
     F5E_REQUIRE(a.ln_rowstats, "gemm_bf16_pp: the large-M AdaLN consumer needs f5e_ln_fuse.row_stats (f5e_ln_finalize)");
     switch (epi) {

@@ -102,6 +102,31 @@ def test_gemm_bf16_gate_residual(ops, M, N, K, rps, hint):
     assert gate_view.shape == (2, N)
 
 
+@pytest.mark.parametrize("hint", [9, 89])
+def test_gate_residual_pingpong_lean_and_general_wave_tiles(ops, hint):
+    """256x256 kernel: a wave tile (128 rows) that is fully live and sees ONE gate row takes the lean read-modify-write (also
+    across a sequence boundary); one with masked rows, rows past M or two gate rows takes the general path.  Both in one
+    launch, against the fp32 reference; masked rows must stay bit-identical."""
+    rps, N, K = 300, 512, 256
+    for gate_rows, lens_l in [(1, [300, 300, 170, 300, 300]), (2, [300, 300, 300, 300, 300]), (1, [300] * 5)]:
+        S = len(lens_l)
+        M = S * rps
+        a = torch.randn(M, K, generator=g(70)).to(BF)
+        w = (torch.randn(N, K, generator=g(71)) / math.sqrt(K)).to(BF)
+        b = torch.randn(N, generator=g(72))
+        x = torch.randn(M, N, generator=g(73))
+        gate = torch.randn(gate_rows, N, generator=g(74))
+        lens = torch.tensor(lens_l, dtype=torch.int32)
+        lin = a.float() @ w.float().T + b
+        seq = torch.arange(M) // rps
+        live = (torch.arange(M) % rps) < lens[seq]
+        ref = torch.where(live[:, None], x + gate[seq % gate_rows] * lin, x)
+        xd = dev(x)
+        ops.gemm_bf16_gate_residual(dev(a), dev(w), dev(b), xd, dev(gate), rps, seq_len=dev(lens), tile_hint=hint)
+        close(xd, ref, 1e-4, 2e-4, f"gate residual {gate_rows} {lens_l}")
+        assert torch.equal(xd.cpu()[~live], x[~live])
+
+
 @pytest.mark.parametrize("S,N,H,rope_heads,K,hint", [(2, 469, 16, 16, 1024, 0), (3, 70, 2, 1, 128, 0), (2, 469, 16, 16, 1024, 9),
                                                      (3, 150, 12, 1, 768, 9), (2, 469, 16, 16, 1024, 89), (3, 150, 12, 1, 768, 89)])
 def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
