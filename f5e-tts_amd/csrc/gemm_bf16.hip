@@ -43,12 +43,20 @@ __device__ __forceinline__ void wait_stages(int nst) {
 
 // BK = K-step: 64 (128-byte LDS rows, two rows per 256-byte bank line: swizzle (row >> 1) & 7) or 128 (256-byte rows = one
 // bank line each: swizzle row & 15; kept as a tuning parameter, no shipped instantiation uses it -- see dispatch()).
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int BK = 64>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
+//
+// SK = 2 (intra-workgroup split-K, gate+residual launches with at most one workgroup per CU): a second group of WGM x WGN
+// waves runs the upper half of K through its own LDS ring, the two accumulator sets meet in LDS in a fixed order (group 0 +
+// group 1: deterministic, unlike atomics) and group 0 runs the epilogue.  Why: at M = 938 the out-projection and FF2 are 240
+// tiles on 256 CUs, and what a lone 4-wave workgroup draws through its LDS-DMA ring (32 GB/s at FF2) is bounded by the
+// bytes it keeps in flight over the load latency, not by the CU: FF1, with two workgroups per CU, moves 48 GB/s per CU.
+// Opt-in (see dispatch()): it pays with HBM-resident weights, not behind the Infinity-Cache prefetch of the block chain.
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int BK = 64, int SK = 1>
+__global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                   // bytes per LDS row
   auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (row & 15); };
-  constexpr int NT = 64 * WGM * WGN;  // threads: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
+  constexpr int NT = 64 * WGM * WGN;  // threads of one K group: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
+  static_assert(SK == 1 || (SK == 2 && EPI == EPI_GATE_RES && FUSE != 1 && DBG == 0), "split-K: gate+residual launches only");
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -56,9 +64,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int TM = WM / 16, TN = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = SK == 1 ? 0 : wave_all / (WGM * WGN);   // K group (wave-uniform)
+  const int wave = SK == 1 ? wave_all : wave_all % (WGM * WGN);
+  const int tid = SK == 1 ? (int)threadIdx.x : (int)threadIdx.x % NT;   // thread index inside the K group
   unsigned long long* trc = nullptr;
   if constexpr (DBG == 3) {
     trc = a.trace + (size_t)blockIdx.x * 48;
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
   if (NT == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
-    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
+    if (grp == 0) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
     return;
   }
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
@@ -122,12 +132,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     const int gr = min(n0 + row, a.N - 1);
     w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
   }
+  const int KT = a.K / (BK * SK);       // K-steps of this group; group g owns K-tiles [g KT, (g + 1) KT)
+  char* const ring = smem + grp * (NSTAGE * STAGE);
+  const int k_first = grp * KT * BK;
   auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE;
+    char* base = ring + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + k_first + kt * BK, base + (wave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + k_first + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
   };
 
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
@@ -143,7 +156,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
   static_assert(NSTAGE >= 2 && NSTAGE <= 8 && (NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
-  const int KT = a.K / BK;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < KT) stage(s, s);
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
     if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
     if (DBG != 2 && kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
-    const char* As = smem + buf * STAGE;
+    const char* As = ring + buf * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < (DBG == 1 ? 0 : BK / 32); ++kk) {
@@ -265,7 +277,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
 
   if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
-  float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // 1 KiB behind the ring (FUSE != 0 launches only)
+  float* fuse_lds = (float*)(smem + SK * NSTAGE * STAGE);  // 1 KiB behind the ring(s) (FUSE != 0 launches only)
+  if constexpr (SK == 2) {
+    // the two K halves meet in LDS (group 0's ring, idle now): 4 KiB per wave, lane-linear 16-byte slots
+    __builtin_amdgcn_s_barrier();  // every wave is past its last ds_read of the rings
+    char* xch = smem + wave * (TM * TN * 1024) + lane * 16;
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) *(f32x4*)(xch + (i * TM + j) * 1024) = acc[i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) return;  // a wave that has ended no longer counts at the workgroup's later barriers
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += *(const f32x4*)(xch + (i * TM + j) * 1024);
+  }
   if (FUSE == 1) {
     // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
     // M2 = sum_p M2_p + 64 sum_p (mean_p - mean)^2, rstd = rsqrt(M2 / K + eps)
@@ -465,8 +495,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int BK = 64>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int BK = 64, int SK = 1>
 int launch(GemmArgs& a, hipStream_t st) {
+  F5E_REQUIRE(a.K % (BK * SK) == 0, "gemm_bf16: K=%d is not a multiple of %d (split-K %d)", a.K, BK * SK, SK);
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.m_major = a.M > a.N;
@@ -476,10 +507,11 @@ int launch(GemmArgs& a, hipStream_t st) {
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
   const int grid = a.n_main + ((WGM * WGN == 4 && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
   if (grid == a.n_main) a.pf = F5ePrefetch{};
-  constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
+  constexpr int lds = SK * NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK, SK>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK, SK>), dim3(grid), dim3(64 * WGM * WGN * SK), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -513,6 +545,20 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       // (K-step 128 -- template parameter BK -- was measured here for the one-workgroup-per-CU launches: out-projection /
       // FF2 12.8 / 17.0 us with BK 64, 13.6 / 17.8 with BK 128 x 3 stages, 12.8 / 16.9 with BK 128 x 2 stages: the lone
       // workgroup's K loop is bound by the ~65 GB/s a CU's LDS-DMA path delivers, not by the number of steps.)
+      if (sel == 5) {  // intra-workgroup split-K (hint 5 + 10 * stages)
+        if (ns == 4) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 64, 2>(a, st);
+        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 64, 2>(a, st);
+      }
+      // Intra-workgroup split-K is OFF by default (F5E_SPLITK=1 / hints 35, 45 switch it on).  Stand-alone with weights
+      // streaming from HBM it wins (tools/gemm_tune.py at M = 938: out-projection 10.4 -> 9.8 us, FF2 12.3 -> 11.0), but in
+      // the block chain, where the weights were prefetched into the Infinity Cache and the launch also hosts prefetch
+      // workgroups, it loses: C2 47.7 vs 46.0 ms per pass (same box, two runs each; out-projection 13.7 vs 12.6 us, FF2 17.5
+      // vs 16.7 with launch gaps).
+      static const int splitk = getenv("F5E_SPLITK") ? atoi(getenv("F5E_SPLITK")) : 0;
+      if (splitk && sel == 0 && blocks(64, 64) <= 256 && a.K >= 1024 && a.K % 128 == 0) {
+        if (a.K >= 2048) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 64, 2>(a, st);
+        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 64, 2>(a, st);
+      }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
@@ -524,6 +570,12 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   // 128x128 ring kernel measured on the four DiT shapes (tools/gemm_tune.py M 21,9): M = 7.5k ring kernel ahead by 0-40 %,
   // M = 13k ping-pong ahead by 5-18 %, M = 30k by 8-37 %: it takes over at 44 row tiles of 256, whatever N.
   if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
+  if constexpr (EPI == EPI_GATE_RES) {
+    if (sel == 5) {  // intra-workgroup split-K (hint 5 + 10 * stages)
+      if (ns == 4) return launch<64, 64, EPI, 4, 2, 2, 0, 0, 64, 2>(a, st);
+      return launch<64, 64, EPI, 3, 2, 2, 0, 0, 64, 2>(a, st);
+    }
+  }
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
   if (sel <= 0) {
     // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and

@@ -75,7 +75,10 @@ def test_gemm_bf16_identity_asymmetric(ops):
 
 
 @pytest.mark.parametrize("M,N,K,rps,hint", [(938, 1024, 1024, 469, 0), (200, 256, 512, 50, 0), (938, 1024, 2048, 469, 9),
-                                            (600, 768, 256, 100, 9), (938, 1024, 2048, 469, 89), (600, 768, 256, 100, 89)])
+                                            (600, 768, 256, 100, 9), (938, 1024, 2048, 469, 89), (600, 768, 256, 100, 89),
+                                            # hints 35 / 45 = intra-workgroup split-K (two K halves, reduced in LDS), 3 / 4 stages
+                                            (938, 1024, 2048, 469, 45), (938, 1024, 1024, 469, 35), (200, 256, 128, 50, 35),
+                                            (600, 768, 256, 100, 45)])
 def test_gemm_bf16_gate_residual(ops, M, N, K, rps, hint):
     S = M // rps
     a = torch.randn(M, K, generator=g(4)).to(BF)
@@ -538,7 +541,9 @@ def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     (2, 469, 1024, 3072, 0.0, False, 0), (2, 100, 768, 1536, 0.7, True, 0), (1, 33, 1024, 100, 0.3, False, 0),
     # hint 9 = the 256 x 256 ping-pong kernel (what large-M launches pick by themselves): partial row tiles, two sequences
     # inside one wave's 128 rows, masked rows, D = 768 (12 statistics tiles), a skinny consumer (N = 100)
-    (2, 469, 1024, 3072, 0.0, False, 9), (3, 150, 768, 1536, 0.7, True, 9), (1, 300, 1024, 100, 0.3, False, 9)])
+    (2, 469, 1024, 3072, 0.0, False, 9), (3, 150, 768, 1536, 0.7, True, 9), (1, 300, 1024, 100, 0.3, False, 9),
+    # hints 35 / 45: the producer as intra-workgroup split-K (the consumers ignore the hint)
+    (2, 469, 1024, 3072, 0.0, False, 45), (2, 100, 768, 1536, 0.7, True, 35)])
 def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     """LayerNorm+modulate folded into the GEMMs either side of it (f5e_ln_fuse): adaln_pre / the gate+residual producer
     -> consumer linear, against LN(x)(1+scale)+shift -> linear in fp32 (reference modules.py:308-314 + :452-454,

@@ -1,1 +1,1 @@
-python -m pytest tests/test_ops_gpu.py -q -x -k "gemm or gate or pingpong or pp or fused" 2>&1 | tail -2 && python tools/pp_timeline.py 60032 qkv && python tools/pp_timeline.py 60032 out && python tools/pp_timeline.py 60032 ff1
+python -m pytest tests/test_ops_gpu.py -q -x -k "gate_residual or fused_adaln_chain" 2>&1 | tail -3 && ONLY=OUT,FF2 python tools/gemm_tune.py 938 33,43,35,45
