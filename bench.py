@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the roofline_c3 leg of the default run")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel eagerly (no hipGraph): for rocprofv3 --pmc passes, which have hung on graph replays")
     ap.add_argument("--streams", type=int, default=4,
                     help="extra leg (1 GPU only, reported as `concurrent`, never as `value`): this many host threads sample "
                          "batch-1 utterances concurrently on one model; 0 skips it")
@@ -151,6 +153,8 @@ def main():
         dit = DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4, text_num_embeds=2545)
         dit.load_state_dict(sd, strict=True)
         cfm = CFM(transformer=dit).cuda().eval()
+    if args.eager:
+        cfm.use_graph = False
     vs = SY.init_vocos_state()
     voc = Vocos()
     voc.load_state_dict(vs, strict=False)

@@ -7,18 +7,25 @@ tag=$1
 R=$(pwd)
 C2="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --steps 5 --warmup 2"
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$SKIP_STATS" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_c2 -o c2 -- python3 $R/bench.py $C2 > $R/gpurun_out/${tag}_prof_c2.json 2> $R/gpurun_out/${tag}_prof_c2.err || { echo "prof c2 failed"; tail -3 $R/gpurun_out/${tag}_prof_c2.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_c3 -o c3 -- python3 $R/bench.py --workload C3 --no-cpu-baseline --no-roofline --streams 0 --steps 2 --warmup 1 > $R/gpurun_out/${tag}_prof_c3.json 2> $R/gpurun_out/${tag}_prof_c3.err || { echo "prof c3 failed"; exit 1; }
-export F5E_LOOP_GRAPH=0   # counter collection crashes (SIGSEGV inside rocprofv3) on the 3700-node whole-loop graph: PMC passes replay the one-step graph
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- python3 $R/bench.py $C2 > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.err || { echo "pmc fetch failed"; tail -3 $R/gpurun_out/${tag}_pmc_fetch.err; exit 1; }
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o w -- python3 $R/bench.py $C2 > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.err || { echo "pmc write failed"; exit 1; }
+fi
+# Counter passes launch eagerly (--eager): counter collection crashed (SIGSEGV inside rocprofv3) on the 3700-node whole-loop
+# graph and once hung on replays of the one-step graph; per-kernel counters do not depend on how a kernel was launched.
+PMC="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --steps 2 --warmup 1 --eager"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- python3 $R/bench.py $PMC > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.err || { echo "pmc fetch failed"; tail -3 $R/gpurun_out/${tag}_pmc_fetch.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o w -- python3 $R/bench.py $PMC > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.err || { echo "pmc write failed"; exit 1; }
 cd $R
 python3 tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_traffic_c2.json
 for w in c2 c3; do
+  [ -n "$SKIP_STATS" ] && continue
   f=$(find gpurun_out/${tag}_prof_$w -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/${tag}_kernel_stats_$w.csv
   python3 tools/prof_summary.py gpurun_out/${tag}_prof_$w 18
 done
+if [ -z "$SKIP_STATS" ]; then
 python3 tools/hbm_kernels.py gpurun_out/${tag}_kernel_stats_c2.csv C2 gpurun_out/${tag}_hbm_kernels_c2.json
 python3 tools/hbm_kernels.py gpurun_out/${tag}_kernel_stats_c3.csv C3 gpurun_out/${tag}_hbm_kernels_c3.json
+fi
 # keep the merged scratch small: raw traces stay on the box
-find gpurun_out/${tag}_prof_c2 gpurun_out/${tag}_prof_c3 gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write -type f -size +2M -delete
+for d in gpurun_out/${tag}_prof_c2 gpurun_out/${tag}_prof_c3 gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write; do [ -d $d ] && find $d -type f -size +2M -delete; done; true

@@ -73,5 +73,7 @@ for r in range(16):
 m = t[:, 1, 3] > 0
 mhz = ((cyc[m, 1, 1] - cyc[m, 1, 0]) / (t[m, 1, 2] - t[m, 1, 1])).mean()
 print(f"shader clock inside the K loop of round 1: {float(mhz):.0f} MHz (s_memtime ticks / s_memrealtime us)")
+ep = (t[:, :, 3] - t[:, :, 2])[t[:, :, 3] > 0].sort().values
+print("epilogue over all tiles: " + "  ".join(f"p{q}={float(ep[int(q / 100 * (len(ep) - 1))]):.2f}" for q in (5, 25, 50, 75, 95)) + " us")
 last = t[:, :, 3].max() - t0
 print(f"last epilogue issued at {float(last):.1f} us after the first entry")
