@@ -786,6 +786,245 @@ int launch_pp2_t(GemmArgs& a, hipStream_t st) {
   return F5E_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third schedule ("pp3"): 4 waves, 256 x 256 tile, ONE wave per SIMD with a 128 x 128 wave tile.
+//
+// Why: the 8-wave kernel's K loop is bound by LDS traffic and, through the power cap, by energy per flop (the
+// shader clock sits at 1.4-2.0 GHz inside the loop).  A 128 x 64 wave tile pulls 0.0234 B of fragments out of LDS per
+// flop; 128 x 128 pulls 0.0156 (-33 %): 128 KiB instead of 192 KiB of ds_read per 64-deep K-tile and CU.  128 x 128 fp32
+// accumulators are 256 registers per lane: with ONE wave per SIMD a wave owns the whole 512-entry file, the accumulators
+// live in the AGPR half (MFMA reads / writes them there) and 256 VGPRs stay for two fragment sets + addresses.  Nothing
+// else shares the SIMD, so the wave hides its own latencies: the ds_reads of K-step s + 1 are issued inside the 64 MFMAs
+// (1024 matrix-pipe cycles) of step s.
+//
+// Geometry.  wave = wr * 2 + wc owns rows [128 wr, +128) x columns [128 wc, +128).  K-step = 32 (one 16x16x32 operand
+// per 16 rows): a stage is 32 KiB = A part (256 rows x 64 B) + W part (256 rows x 64 B), ring of FIVE stages = 160 KiB.
+// LDS row = 4 chunks of 16 B; physical chunk = logical chunk ^ ((row >> 2) & 3), applied on the DMA source side and on
+// the ds_read_b128 (the 16 lanes of a read group then cover all 16 bank quads of a 256-byte bank line).
+//
+// Step s (stage s in slot s % 5, fragment set s & 1):
+//     lgkmcnt(0)                         set s & 1 complete (its reads were issued in step s - 1)
+//     16 MFMAs
+//     wait until stage s + 1 has landed (the two younger stages stay in flight), s_barrier
+//         -> every wave's share of stage s + 1 is visible, and every wave is past the lgkmcnt(0) of step s, i.e. done
+//            reading stage s: its slot is free
+//     issue stage s + 5 into the slot of stage s;  ds_read set (s + 1) & 1 from stage s + 1
+//     48 MFMAs
+// RAW: a stage is read only after the wait + barrier that retired it.  WAR: a slot is re-staged only after the barrier
+// that follows every wave's lgkmcnt(0) on the reads of its previous content.
+template <int EPI>
+__device__ __forceinline__ void pp3_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles, int iter = 0) {
+  constexpr int STG = 32768, NSLOT = 5;
+  const int tid = threadIdx.x;
+  auto stamp = [&](int k) {   // tools build only (a.trace stays null otherwise): tools/pp_timeline.py
+#ifdef F5E_TOOLS
+    if (tid == 0 && a.trace && iter < 16) {
+      a.trace[((size_t)blockIdx.x * 16 + iter) * 4 + k] = __builtin_amdgcn_s_memrealtime();
+      if (k == 1 || k == 2) a.trace[(size_t)gridDim.x * 64 + ((size_t)blockIdx.x * 16 + iter) * 2 + (k - 1)] = __builtin_readcyclecounter();
+    }
+#endif
+  };
+  stamp(0);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  int bid = phys_id;
+  {
+    const int nblk = n_tiles;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  int tile_m, tile_n;
+  if (a.m_major) {
+    tile_m = bid / a.tiles_n;
+    tile_n = bid - tile_m * a.tiles_n;
+  } else {
+    tile_n = bid / a.tiles_m;
+    tile_m = bid - tile_n * a.tiles_m;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // DMA sources: thread tid moves chunks ci = tid + 256 j (j < 4) of the A part and of the W part; row = ci >> 2
+  const bf16* asrc[4];
+  const bf16* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = tid + 256 * j, row = ci >> 2, lc = (ci & 3) ^ ((row >> 2) & 3);
+    asrc[j] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + lc * 8;
+    wsrc[j] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + lc * 8;
+  }
+  const int S = a.K / 32;
+  auto issue = [&](int slot, int st) {
+    char* dst = smem + slot * STG + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(asrc[j] + st * 32, dst + j * 4096);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(wsrc[j] + st * 32, dst + 16384 + j * 4096);
+  };
+
+  f32x4 accL[4][8], accH[4][8];  // columns [0, 64) / [64, 128) of the wave tile, the layout pp_epilogue takes
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accL[i][j] = accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fo = (fq ^ ((fr >> 2) & 3)) << 4;
+  const int xoff = (wr * 128 + fr) * 64 + fo, woff = 16384 + (wc * 128 + fr) * 64 + fo;
+  bf16x8 xf0[8], wf0[8], xf1[8], wf1[8];
+  auto read_set = [&](const char* slot, bf16x8 (&xf)[8], bf16x8 (&wf)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(slot + xoff + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wf[i] = *(const bf16x8*)(slot + woff + i * 1024);
+  };
+  auto mfma_rows = [](auto i0_c, auto n_c, f32x4 (&accL)[4][8], f32x4 (&accH)[4][8], bf16x8 (&xf)[8], bf16x8 (&wf)[8]) {  // column blocks [i0, i0 + n) of the 8
+    constexpr int i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
+#pragma unroll
+    for (int i = i0; i < i0 + n; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // inline asm with an AGPR constraint: left to itself hipcc keeps part of the 256 accumulators in VGPRs and shuffles
+        // them through v_accvgpr_write around every MFMA (4 VALU issues per 16-cycle MFMA).  Hazards the compiler cannot
+        // see inside asm: an accumulator is touched once per 64 MFMAs (no back-to-back dependency), and the loop is
+        // followed by explicit wait states before the epilogue reads the AGPRs.
+        if (i < 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accL[i][j]) : "v"(wf[i]), "v"(xf[j]));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accH[i - 4][j]) : "v"(wf[i]), "v"(xf[j]));
+      }
+  };
+  auto wait_young = [&](int stages) {  // all but the `stages` youngest stages (8 DMAs each) of this wave have landed
+    if (stages >= 3) wait_vm<24>();
+    else if (stages == 2) wait_vm<16>();
+    else if (stages == 1) wait_vm<8>();
+    else wait_vm<0>();
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C2 = std::integral_constant<int, 2>;
+  using C6 = std::integral_constant<int, 6>;
+
+  // prologue: stages 0 .. 3; stage 0 must have landed before the first reads
+  int n_issued = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < S) { issue(t, t); ++n_issued; }
+  wait_young(n_issued - 1);
+  __builtin_amdgcn_s_barrier();
+  stamp(1);
+  read_set(smem, xf0, wf0);
+
+  int slot_next = 1;   // slot of stage s + 1
+  int slot_free = 4;   // slot that stage s + 4 goes into at step s: (s + 4) % 5
+  auto advance = [&]() {
+    slot_next = slot_next == NSLOT - 1 ? 0 : slot_next + 1;
+    slot_free = slot_free == NSLOT - 1 ? 0 : slot_free + 1;
+  };
+  auto mf = [](f32x4 (&accL)[4][8], f32x4 (&accH)[4][8], bf16x8 (&xf)[8], bf16x8 (&wf)[8], int i, int j) {
+    if (i < 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accL[i][j]) : "v"(wf[i]), "v"(xf[j]));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accH[i - 4][j]) : "v"(wf[i]), "v"(xf[j]));
+  };
+  // Main-loop step (s + 4 < S): with one wave per SIMD nothing else feeds the matrix pipe, so the step's 8 LDS-DMAs and 16
+  // ds_reads are spread BETWEEN its MFMAs (two MFMAs = 32 pipe cycles per memory instruction) instead of issued in a
+  // bunch during which the pipe would drain; sched_barrier pins each of them in its slot.
+  auto step_full = [&](int s, bf16x8 (&xf)[8], bf16x8 (&wf)[8], bf16x8 (&xn)[8], bf16x8 (&wn)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mfma_rows(C0{}, C2{}, accL, accH, xf, wf);
+    wait_vm<16>();   // stage s + 1 landed; s + 2, s + 3 stay in flight
+    __builtin_amdgcn_s_barrier();
+    char* dst = smem + slot_free * STG + wave * 1024;
+    const char* rd = smem + slot_next * STG;
+    // reads first (the last one is followed by >= 16 MFMAs = 256 pipe cycles before the next step's lgkmcnt(0)), DMAs last
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (g < 8) xn[g] = *(const bf16x8*)(rd + xoff + g * 1024);
+      else wn[g - 8] = *(const bf16x8*)(rd + woff + (g - 8) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(accL, accH, xf, wf, 2 + (g >> 2), (2 * g) & 7);
+      mf(accL, accH, xf, wf, 2 + (g >> 2), (2 * g + 1) & 7);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g < 4) glds16(asrc[g] + (s + 4) * 32, dst + g * 4096);
+      else glds16(wsrc[g - 4] + (s + 4) * 32, dst + 16384 + (g - 4) * 4096);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(accL, accH, xf, wf, 6 + (g >> 2), (2 * g) & 7);
+      mf(accL, accH, xf, wf, 6 + (g >> 2), (2 * g + 1) & 7);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
+  };
+  auto step = [&](int s, bf16x8 (&xf)[8], bf16x8 (&wf)[8], bf16x8 (&xn)[8], bf16x8 (&wn)[8]) {  // tail steps
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mfma_rows(C0{}, C2{}, accL, accH, xf, wf);
+    // stages issued so far: min(s + 3, S - 1) is the youngest (step s - 1 issued stage s + 3); stage s + 1 must have landed
+    const int youngest = s + 3 < S - 1 ? s + 3 : S - 1;
+    wait_young(youngest - (s + 1) > 0 ? youngest - (s + 1) : 0);
+    __builtin_amdgcn_s_barrier();
+    if (s + 4 < S) issue(slot_free, s + 4);
+    if (s + 1 < S) read_set(smem + slot_next * STG, xn, wn);
+    mfma_rows(C2{}, C6{}, accL, accH, xf, wf);
+    advance();
+  };
+  int s = 0;
+  for (; s + 5 < S; s += 2) {   // S is even (K % 64 == 0); both steps of the pair still issue a stage
+    step_full(s, xf0, wf0, xf1, wf1);
+    step_full(s + 1, xf1, wf1, xf0, wf0);
+  }
+  for (; s < S; s += 2) {
+    step(s, xf0, wf0, xf1, wf1);
+    step(s + 1, xf1, wf1, xf0, wf0);
+  }
+  // every wave is past the last step's barrier, i.e. past its last LDS read: the ring is free for the epilogue
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA write -> v_accvgpr_read wait states (asm MFMAs: see mfma_rows)
+  stamp(2);
+  pp_epilogue<EPI, 0, 0, 0>(a, smem, accL, wave * 2, lane, wr, wc * 2, m0, n0);
+  pp_epilogue<EPI, 0, 0, 0>(a, smem, accH, wave * 2 + 1, lane, wr, wc * 2 + 1, m0, n0);
+  stamp(3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_pp3_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
+  const int extra = n_tiles % grid;
+  if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
+    const long long slack = (long long)(a.K / 64) * 5000;
+    const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  int iter = 0;
+  for (int p = blockIdx.x; p < n_tiles; p += grid, ++iter) {
+    pp3_tile<EPI>(a, smem, p, n_tiles, iter);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <int EPI>
+int launch_pp3_t(GemmArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  a.m_major = a.M > a.N;
+  a.rps_magic = div_magic_of(a.rows_per_seq);
+  constexpr int lds = 5 * 32768;
+#ifdef F5E_TOOLS
+  a.trace = getenv("F5E_PP_TRACE") ? (unsigned long long*)strtoull(getenv("F5E_PP_TRACE"), nullptr, 0) : nullptr;
+#endif
+  static F5eDeviceOnce lds_once;
+  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp3_kernel<EPI>), lds);
+  int n_cu = f5e_cu_count() / 8 * 8;
+  if (n_cu == 0) n_cu = 8;
+  const char* se = getenv("F5E_PP_STAGGER");
+  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
+  const int n_tiles = a.tiles_m * a.tiles_n;
+  const int grid = n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu;
+  hipLaunchKernelGGL((gemm_bf16_pp3_kernel<EPI>), dim3(grid), dim3(256), lds, st, a);
+  F5E_LAUNCH_CHECK("gemm_bf16_pp3");
+  return F5E_OK;
+}
+
 template <int EPI, int DBG = 0, int FUSE = 0>
 int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
@@ -826,7 +1065,17 @@ int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
       case EPI_F32: return launch_pp2_t<EPI_F32>(a, st);
     }
   }
-  if (dbg == 8) dbg = 0;
+  static const int pp3_env = getenv("F5E_PP3") ? atoi(getenv("F5E_PP3")) : 0;
+  if ((dbg == 11 || (dbg == 0 && pp3_env)) && !a.ln_stats && !a.stats_out) {   // tile_hint 119
+    switch (epi) {
+      case EPI_BF16: return launch_pp3_t<EPI_BF16>(a, st);
+      case EPI_BF16_GELU: return launch_pp3_t<EPI_BF16_GELU>(a, st);
+      case EPI_GATE_RES: return launch_pp3_t<EPI_GATE_RES>(a, st);
+      case EPI_QKV_ROPE: return launch_pp3_t<EPI_QKV_ROPE>(a, st);
+      case EPI_F32: return launch_pp3_t<EPI_F32>(a, st);
+    }
+  }
+  if (dbg == 8 || dbg == 11) dbg = 0;
   if (dbg == 1) return launch_pp_t<EPI_BF16_GELU, 1>(a, st);
   if (dbg == 2) return launch_pp_t<EPI_BF16_GELU, 2>(a, st);
   if (dbg == 3) return launch_pp_t<EPI_BF16_GELU, 3>(a, st);

@@ -47,7 +47,10 @@ def close(a, b, rtol, atol, what=""):
                                         # hint 89 = the two-workgroups-per-CU schedule of the same kernel family (256 x 128 tile,
                                         # 5-slot ring): K = 128 (2 K-tiles: the shortest ring run), odd tile counts, N < tile
                                         (938, 2048, 1024, 89), (700, 768, 512, 89), (300, 100, 128, 89), (256, 256, 128, 89),
-                                        (1300, 512, 2048, 89), (5000, 640, 192, 89)])
+                                        (1300, 512, 2048, 89), (5000, 640, 192, 89),
+                                        # hint 119 = one wave per SIMD with 128 x 128 wave tiles, accumulators in AGPRs ("pp3")
+                                        (938, 2048, 1024, 119), (700, 768, 512, 119), (300, 100, 128, 119), (256, 256, 128, 119),
+                                        (1300, 512, 2048, 119), (5000, 640, 192, 119)])
 def test_gemm_bf16_bias(ops, M, N, K, hint):
     a = torch.randn(M, K, generator=g(1)).to(BF)
     w = (torch.randn(N, K, generator=g(2)) / math.sqrt(K)).to(BF)
@@ -65,7 +68,7 @@ def test_gemm_bf16_bias(ops, M, N, K, hint):
 
 def test_gemm_bf16_identity_asymmetric(ops):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
-    for n, hints in ((128, (1, 2, 3)), (512, (1, 9, 89))):
+    for n, hints in ((128, (1, 2, 3)), (512, (1, 9, 89, 119))):
         a = torch.eye(n).to(BF)
         w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)  # exactly representable, asymmetric
         out = torch.empty(n, n, device="cuda")
@@ -76,6 +79,7 @@ def test_gemm_bf16_identity_asymmetric(ops):
 
 @pytest.mark.parametrize("M,N,K,rps,hint", [(938, 1024, 1024, 469, 0), (200, 256, 512, 50, 0), (938, 1024, 2048, 469, 9),
                                             (600, 768, 256, 100, 9), (938, 1024, 2048, 469, 89), (600, 768, 256, 100, 89),
+                                            (938, 1024, 2048, 469, 119), (600, 768, 256, 100, 119),
                                             # hints 35 / 45 = intra-workgroup split-K (two K halves, reduced in LDS), 3 / 4 stages
                                             (938, 1024, 2048, 469, 45), (938, 1024, 1024, 469, 35), (200, 256, 128, 50, 35),
                                             (600, 768, 256, 100, 45)])
@@ -105,7 +109,7 @@ def test_gemm_bf16_gate_residual(ops, M, N, K, rps, hint):
     assert gate_view.shape == (2, N)
 
 
-@pytest.mark.parametrize("hint", [9, 89])
+@pytest.mark.parametrize("hint", [9, 89, 119])
 def test_gate_residual_pingpong_lean_and_general_wave_tiles(ops, hint):
     """256x256 kernel: a wave tile (128 rows) that is fully live and sees ONE gate row takes the lean read-modify-write (also
     across a sequence boundary); one with masked rows, rows past M or two gate rows takes the general path.  Both in one
@@ -131,7 +135,8 @@ def test_gate_residual_pingpong_lean_and_general_wave_tiles(ops, hint):
 
 
 @pytest.mark.parametrize("S,N,H,rope_heads,K,hint", [(2, 469, 16, 16, 1024, 0), (3, 70, 2, 1, 128, 0), (2, 469, 16, 16, 1024, 9),
-                                                     (3, 150, 12, 1, 768, 9), (2, 469, 16, 16, 1024, 89), (3, 150, 12, 1, 768, 89)])
+                                                     (3, 150, 12, 1, 768, 9), (2, 469, 16, 16, 1024, 89), (3, 150, 12, 1, 768, 89),
+                                                     (2, 469, 16, 16, 1024, 119), (3, 150, 12, 1, 768, 119)])
 def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     inner = H * 64
     n_pad = (N + 63) // 64 * 64
@@ -511,7 +516,7 @@ def test_istft_head_against_reference_istft_head_fixture(ops, tag):
         assert float((out[1].cpu() * env - common[1]).abs().max()) < 2e-4 * float(common[1].abs().max())
 
 
-@pytest.mark.parametrize("hint", [0, 9, 89])
+@pytest.mark.parametrize("hint", [0, 9, 89, 119])
 def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     """qk_norm = 'rms_norm' (reference modules.py:464-467): RMSNorm over the 64-d head before RoPE, q and k only."""
     S, N, H, K = 2, 150, 12, 768
