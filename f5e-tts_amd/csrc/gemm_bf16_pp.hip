@@ -277,34 +277,54 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
       const int rows_valid = min(128, a.M - mbase);
       const int seq0 = mbase / a.rows_per_seq, pos0 = mbase - seq0 * a.rows_per_seq;
       const int rb = min(128, a.rows_per_seq - pos0);  // rows [0, rb) are sequence seq0, [rb, 128) sequence seq0 + 1
-      const int dl = lane >> 1, hk = lane & 1;
+      // A 16-byte piece = 8 keys of one d = two hardware-transposed LDS reads (ds_read_b64_tr_b16: the 16 lanes of a group
+      // supply the addresses of 4 rows x 16 columns and lane i gets column i of the 4 rows) instead of eight 2-byte reads:
+      // group g4 = lane >> 4 takes d block g4 & 1 and key half hk = g4 >> 1, lane i of the group the d column i.  The 64
+      // lanes of a store instruction still cover one contiguous 1 KiB ([32 d][2 h][8 keys]).  Every lane supplies a valid
+      // address (rows clamped into the segment): the instruction needs EXEC all ones, the branches around it are uniform.
+      using s16x4 = short __attribute__((ext_vector_type(4)));
+      const int g4 = lane >> 4, i16 = lane & 15, d16 = g4 & 1, hk = g4 >> 1, tq = (lane >> 2) & 3, tp = lane & 3;
       for (int seg = 0; seg < 2; ++seg) {
         const int rstart = seg == 0 ? 0 : rb;
         const int rcount = min(seg == 0 ? rb : 128 - rb, rows_valid - rstart);
         if (rcount <= 0) break;
         const int pstart = seg == 0 ? pos0 : 0;
         bf16* vb = a.vt + ((size_t)(seq0 + seg) * a.heads + head) * a.n_pad * 64;
+#pragma unroll 3
         for (int G = pstart >> 4; G <= (pstart + rcount - 1) >> 4; ++G) {
           const bool whole = G * 16 >= pstart && G * 16 + 15 < pstart + rcount;
+          const int rel = rstart + G * 16 - pstart + 4 * hk + tq;   // LDS row of key 16 G + 4 hk + tq
+          const int ra = min(max(rel, rstart), rstart + rcount - 1), rb8 = min(max(rel + 8, rstart), rstart + rcount - 1);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const int d = dt * 32 + dl;
-            bf16x8 piece;
-            bool ok[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int pos = G * 16 + 8 * (j >> 2) + 4 * hk + (j & 3);
-              ok[j] = pos >= pstart && pos < pstart + rcount;
-              const int r = ok[j] ? rstart + pos - pstart : 0;
-              piece[j] = *(const bf16*)(reg + r * 128 + (((d >> 3) ^ (r & 7)) << 4) + (d & 7) * 2);
-            }
-            bf16* dst = vb + ((size_t)(G * 2 + dt) * 32 + dl) * 16 + hk * 8;
+            const int d0 = dt * 32 + d16 * 16 + 4 * tp;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(reg + ra * 128 + (((d0 >> 3) ^ (ra & 7)) << 4) + (d0 & 7) * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(reg + rb8 * 128 + (((d0 >> 3) ^ (rb8 & 7)) << 4) + (d0 & 7) * 2));
+            bf16* dst = vb + ((size_t)(G * 2 + dt) * 32 + d16 * 16 + i16) * 16 + hk * 8;
             if (whole) {
-              *(bf16x8*)dst = piece;
+              *(uint4*)dst = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
             } else {
+              // first / last group of a segment: the other keys belong to a neighbouring wave.  Each half of the piece is 4
+              // consecutive keys: whole halves leave as 8 bytes, aligned pairs as 4 (sequence starts are even whenever
+              // rows_per_seq is), single keys as 2
 #pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (ok[j]) dst[j] = piece[j];
+              for (int hf = 0; hf < 2; ++hf) {
+                const s16x4 v4 = hf ? hi : lo;
+                const int k0 = G * 16 + 8 * hf + 4 * hk;
+                short* d4 = (short*)dst + 4 * hf;
+                const bool o0 = k0 >= pstart && k0 < pstart + rcount, o1 = k0 + 1 >= pstart && k0 + 1 < pstart + rcount;
+                const bool o2 = k0 + 2 >= pstart && k0 + 2 < pstart + rcount, o3 = k0 + 3 >= pstart && k0 + 3 < pstart + rcount;
+                if (o0 && o3) {
+                  *(s16x4*)d4 = v4;
+                } else {
+                  if (o0 && o1) *(unsigned*)d4 = ((const unsigned*)&v4)[0];
+                  else { if (o0) d4[0] = v4[0]; if (o1) d4[1] = v4[1]; }
+                  if (o2 && o3) *(unsigned*)(d4 + 2) = ((const unsigned*)&v4)[1];
+                  else { if (o2) d4[2] = v4[2]; if (o3) d4[3] = v4[3]; }
+                }
+              }
             }
           }
         }
