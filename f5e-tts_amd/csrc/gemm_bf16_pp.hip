@@ -113,7 +113,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
       return;
     }
   }
-  if constexpr (EPI == EPI_GATE_RES && FUSE == 0) {
+  if constexpr (EPI == EPI_GATE_RES && FUSE != 1) {
     // Lean read-modify-write for the common wave tile: all 128 rows inside [0, M) and inside their sequences' lengths, one
     // gate row.  Sequence, position, lengths and gate row are per-wave scalars (the wave's rows touch at most two sequences
     // when rows_per_seq >= 128), so the per-row division / modulo / loop / predicate of the general path below (~3000
@@ -135,6 +135,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
         const int c = lane & 15, rq = lane >> 4;
         const f32x4 ga = *(const f32x4*)(a.gate + eoff + (size_t)grow_a * a.gate_stride + nbase + c * 4);
         const f32x4 bc = a.bias ? *(const f32x4*)(a.bias + nbase + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 nsq = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FUSE == 2) nsq = *(const f32x4*)(a.next_scale + eoff + nbase + c * 4) + 1.0f;  // gate_rows == 1
         // uniform base + 32-bit byte offset per row (a 128-row tile of fp32 spans < 2^31 bytes).  The row stride is made
         // opaque per tile: otherwise the row offsets are hoisted out of the persistent tile loop as loop invariants, live
         // (and spilled) across the K loop
@@ -161,7 +163,26 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
 #pragma unroll
           for (int b = 0; b < 16; ++b) {
             const f32x4 v = *(const f32x4*)(reg + ((rd0 ^ ((b & 3) << 6)) + b * 1024));
-            *(f32x4*)(xbase + (off0 + (unsigned)(half * 64 + b * 4) * rstride)) = xv[b] + ga * (v + bc);
+            const f32x4 xn = xv[b] + ga * (v + bc);
+            *(f32x4*)(xbase + (off0 + (unsigned)(half * 64 + b * 4) * rstride)) = xn;
+            if constexpr (FUSE == 2) {
+              // AdaLN producer (same contract as the general path below): xs for the next linear and (mean, M2) of x_new
+              // over this wave's 64 columns; the 16 lanes of a row are one DPP row
+              const int row = mbase + half * 64 + b * 4 + rq;
+              const f32x4 y = xn * nsq;
+              *(bf16x4*)(a.xs_out + (size_t)row * a.ld_xs + nbase + c * 4) = f2bf4(y[0], y[1], y[2], y[3]);
+              float sm = (xn[0] + xn[1]) + (xn[2] + xn[3]);
+              sm = add_xor2(add_xor1(sm));
+              sm += dpp_f32<0x124>(sm);
+              sm += dpp_f32<0x128>(sm);
+              const float mw = sm * (1.0f / 64.0f);
+              const f32x4 dv = xn - mw;
+              float q2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+              q2 = add_xor2(add_xor1(q2));
+              q2 += dpp_f32<0x124>(q2);
+              q2 += dpp_f32<0x128>(q2);
+              if (c == 0) *(f32x2*)(a.stats_out + ((size_t)row * (a.N >> 6) + (nbase >> 6)) * 2) = f32x2{mw, q2};
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the region is overwritten
         }
