@@ -385,3 +385,22 @@ def test_mish_closed_form_matches_the_definition():
     err = (y.double() - ref).abs()
     assert bool((err <= 1e-7 + 1e-6 * ref.abs()).all()), float(err.max())
 
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md section D is the one table of F5E_* switches: every variable the sources read must be in it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'(?:getenv\(|environ\.get\(|environ\[)\s*"(F5E_[A-Z0-9_]+)"')
+    used = set()
+    for base, _, files in os.walk(os.path.join(root, "f5e-tts_amd")):
+        if "build" in base.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                used |= set(pat.findall(open(os.path.join(base, f), errors="ignore").read()))
+    used |= set(pat.findall(open(os.path.join(root, "bench.py")).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(v for v in used if f"`{v}`" not in doc)
+    assert not missing, f"undocumented environment switches: {missing}"
+    assert len(used) >= 10
