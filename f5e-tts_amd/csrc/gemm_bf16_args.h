@@ -44,6 +44,7 @@ struct GemmArgs {
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
   int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
+  int pp_ngroup;   // gemm_bf16_pp.hip: n-tiles per column group of the tile order (0 = plain m-major)
   F5ePrefetch pf;  // weights of the next kernels, pulled into the Infinity Cache by grid-tail workgroups (small M only)
 };
 

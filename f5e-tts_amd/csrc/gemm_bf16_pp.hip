@@ -460,7 +460,17 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
   int tile_m, tile_n;
-  if (a.m_major) {
+  if (a.m_major && a.pp_ngroup > 0) {
+    // Column groups: all row panels for n-tiles [g G, (g + 1) G), then the next group.  With plain m-major order the 32 CUs
+    // of an XCD work on ~2.7 row panels x ALL n-tiles at once, i.e. on the whole weight matrix (QKV: 6 MB against 4 MB of
+    // L2): the weights stream from the Infinity Cache once per round.  Grouped, an XCD's 32 concurrent tiles are 8 row
+    // panels x G n-tiles: G x 512 KiB of weights stay L2-resident and an activation panel is read once per group.
+    const int G = a.pp_ngroup, per_group = a.tiles_m * G;
+    const int g = bid / per_group, r = bid - g * per_group;
+    const int gw = min(G, a.tiles_n - g * G);   // the last group may be narrower
+    tile_m = r / gw;
+    tile_n = g * G + (r - tile_m * gw);
+  } else if (a.m_major) {
     tile_m = bid / a.tiles_n;
     tile_n = bid - tile_m * a.tiles_n;
   } else {
@@ -1079,6 +1089,8 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
   if (n_cu == 0) n_cu = 8;
   const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
   a.pp_stagger = (se && se[0] == '0') ? 0 : ((se && se[0] == '2') ? 2 : 1);
+  static const int ngroup_env = getenv("F5E_PP_NGROUP") ? atoi(getenv("F5E_PP_NGROUP")) : 4;
+  a.pp_ngroup = (ngroup_env > 0 && a.tiles_n > ngroup_env) ? ngroup_env : 0;
   const int n_tiles = a.tiles_m * a.tiles_n;
 #ifdef F5E_TOOLS
   if (DBG >= 7) a.trace = getenv("F5E_PP_TRACE") ? (unsigned long long*)strtoull(getenv("F5E_PP_TRACE"), nullptr, 0) : nullptr;

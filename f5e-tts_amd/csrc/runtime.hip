@@ -59,7 +59,7 @@ int f5e_graph_end(hipStream_t st, void** graph_exec_out) {
   HIP_TRY(hipStreamEndCapture(st, &g), "hipStreamEndCapture");
   hipGraphExec_t ex = nullptr;
   hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);  // the executable graph keeps what it needs; a failure here would only leak the template
   if (e != hipSuccess) {
     f5e_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
     return F5E_ERR_HIP;
