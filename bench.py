@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the roofline_c3 leg of the default run")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size (experiments; the line says so)")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel eagerly (no hipGraph): for rocprofv3 --pmc passes, which have hung on graph replays")
     ap.add_argument("--streams", type=int, default=4,
@@ -105,6 +106,8 @@ def main():
     global N_REF, N_TOTAL, BATCH, NFE
     if args.workload == "C3":
         N_REF, N_TOTAL, BATCH = 375, 938, 32
+    if args.batch > 0:
+        BATCH = args.batch
     if args.workload == "C4":
         NFE = 16
     if args.workload in ("C4", "C5"):
