@@ -280,6 +280,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
     // into at most two segments (rows_per_seq >= 128) whose first / last group may be partial: those fall back to
     // element stores of the valid keys only (the other keys of the group belong to a neighbouring wave).
     const int inner = a.heads * 64;
+    if (nbase >= a.N) return;  // a wave whose columns lie past 3 * inner (heads not a multiple of 4): nothing to store
     if (nbase >= 2 * inner && a.rows_per_seq >= 128) {
       const int head = (nbase - 2 * inner) >> 6;
       f32x4 bq[4];

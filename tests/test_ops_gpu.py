@@ -80,6 +80,8 @@ def test_gemm_bf16_identity_asymmetric(ops):
 @pytest.mark.parametrize("M,N,K,rps,hint", [(938, 1024, 1024, 469, 0), (200, 256, 512, 50, 0), (938, 1024, 2048, 469, 9),
                                             (600, 768, 256, 100, 9), (938, 1024, 2048, 469, 89), (600, 768, 256, 100, 89),
                                             (938, 1024, 2048, 469, 119), (600, 768, 256, 100, 119),
+                                            (786, 512, 256, 131, 9), (1028, 256, 128, 257, 9),   # odd rows per sequence
+                                            (900, 192, 128, 300, 9), (900, 320, 128, 150, 9), (700, 64, 128, 350, 9),  # N % 256 != 0
                                             # hints 35 / 45 = intra-workgroup split-K (two K halves, reduced in LDS), 3 / 4 stages
                                             (938, 1024, 2048, 469, 45), (938, 1024, 1024, 469, 35), (200, 256, 128, 50, 35),
                                             (600, 768, 256, 100, 45)])
@@ -136,7 +138,12 @@ def test_gate_residual_pingpong_lean_and_general_wave_tiles(ops, hint):
 
 @pytest.mark.parametrize("S,N,H,rope_heads,K,hint", [(2, 469, 16, 16, 1024, 0), (3, 70, 2, 1, 128, 0), (2, 469, 16, 16, 1024, 9),
                                                      (3, 150, 12, 1, 768, 9), (2, 469, 16, 16, 1024, 89), (3, 150, 12, 1, 768, 89),
-                                                     (2, 469, 16, 16, 1024, 119), (3, 150, 12, 1, 768, 119)])
+                                                     (2, 469, 16, 16, 1024, 119), (3, 150, 12, 1, 768, 119),
+                                                     # odd rows per sequence: V^T key groups start at odd offsets (2-byte pieces),
+                                                     # a sequence boundary in every other wave tile
+                                                     (3, 131, 4, 1, 256, 9), (2, 257, 2, 2, 128, 9), (5, 199, 4, 4, 128, 89),
+                                                     # heads not a multiple of 4: the last 256-column tile has waves past 3 * inner
+                                                     (2, 300, 6, 6, 128, 9), (2, 260, 10, 1, 128, 9), (2, 300, 6, 2, 128, 119)])
 def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     inner = H * 64
     n_pad = (N + 63) // 64 * 64
