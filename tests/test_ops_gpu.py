@@ -170,7 +170,8 @@ def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
     close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k")
     close(unq(vt, vi)[:, :, :N], v_ref, 2 ** -7, 4e-3, "v")
-    assert float(unq(q, qi)[:, :, N:].abs().max()) == 0 and float(unq(vt, vi)[:, :, N:].abs().max()) == 0
+    if n_pad > N:   # pad positions are never written
+        assert float(unq(q, qi)[:, :, N:].abs().max()) == 0 and float(unq(vt, vi)[:, :, N:].abs().max()) == 0
 
 
 def pack_qkv(ops, q, k, v, n_pad):
