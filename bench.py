@@ -2,8 +2,13 @@
 """bench.py -- mel-frames/sec of the F5TTS_v1_Base flow-matching hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL is used for barriers + one MAX all-reduce only --
-   utterances are independent)
+  (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process IS one of the N ranks;
+   started plainly with --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+   as a CHILD process before anything touches the GPU, relays the child's JSON line and exits with its code -- the
+   counterpart of the reference's `accelerate launch` (eval/eval_infer_batch.sh:4-6).  RCCL carries barriers, one SUM / MAX
+   all-reduce and one all-gather of per-rank records only -- utterances are independent, SURVEY 8e.  Every rank runs the
+   same per-GPU workload (weak scaling, the same metric at every N); `scaling_c4` adds the STRONG-scaling record on
+   BASELINE's scaling config: a fixed total of C4 utterances LPT-split over the ranks.)
 
 A "step" is one full pass of the hot path over one batch: log-mel front-end (HIP STFT) -> 32 Euler steps of the
 CFG-batched DiT (hipGraph replay) -> stitch -> Vocos decode on the GPU, for BASELINE config C2:
@@ -84,9 +89,116 @@ def median(v):
     return s[len(s) // 2]
 
 
+def c4_fixed_total(total, rank, world, dist, make_input, run_one, sync, device):
+    """Strong-scaling leg on BASELINE's scaling config (C4: eval_infer_batch-style stream, NFE 16): a FIXED total of `total`
+    utterances (lengths from tests/golden/c4_durations.csv), LPT-split over the ranks on the analytic FLOP cost (SURVEY
+    8e; reference eval_infer_batch.py:184-220 splits the same list with split_between_processes), every rank runs its
+    share one utterance per call, barrier either side, wall = MAX over ranks.  No data-path collective."""
+    from f5e_tts_amd.eval.eval_infer_batch import c4_work_list, flop_fwd, lpt_partition, reduce_job_totals
+    utts = c4_work_list(os.path.join(ROOT, "tests", "golden", "c4_durations.csv"), total)
+    parts = lpt_partition([flop_fwd(t) for _, t in utts], world)
+    mine = [utts[i] for i in parts[rank]]
+    inputs = [make_input(r, t) for r, t in mine]
+    for x in inputs[:2]:               # kernels / allocator warm; the per-length graph captures stay inside the timed region,
+        run_one(x)                     # as they are in a real eval run over distinct lengths
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for x in inputs:
+        run_one(x)
+    sync()
+    mine_s = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    red = reduce_job_totals(dist, sum(t for _, t in mine), sum(t - r for r, t in mine), mine_s, device)
+    assert int(red["frames"]) == sum(t for _, t in utts) and len(red["per_rank_frames"]) == world
+    return {"workload": f"C4 fixed total: {total} utterances (610-1390 frames), one per call, euler NFE=16, CFG=2.0, "
+                        f"LPT-split over {world} rank(s)", "scaling": "strong", "utterances": total,
+            "mel_frames_per_sec": round(red["frames"] / red["seconds"], 1), "seconds": round(red["seconds"], 3),
+            "ms_per_utterance_per_gpu": round(red["seconds"] / (total / world) * 1e3, 2),
+            "per_rank_utterances": [len(p) for p in parts],
+            "per_rank_frames": [int(x) for x in red["per_rank_frames"]],
+            "per_rank_seconds": [round(x, 3) for x in red["per_rank_seconds"]]}
+
+
+def stub_main(args, rank, world, distributed):
+    """--stub: the launch / partition / reduction skeleton of main() with no GPU behind it (gloo, a pass = 2 ms sleep)."""
+    import torch.distributed as dist
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world == args.gpus
+    d = dist if distributed else None
+    from f5e_tts_amd.eval.eval_infer_batch import reduce_job_totals
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    if d:
+        d.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    if d:
+        d.barrier()
+    elapsed = time.perf_counter() - t0
+    red = reduce_job_totals(d, args.steps * N_TOTAL * BATCH, args.steps * BATCH * (N_TOTAL - N_REF), elapsed, "cpu")
+    c4 = None
+    if args.c4_total > 0:
+        c4 = c4_fixed_total(args.c4_total, rank, world, d, lambda r, t: (r, t), lambda x: time.sleep(0.0005),
+                            lambda: None, "cpu")
+    if rank == 0:
+        assert red["world_size"] == world and len(red["per_rank_frames"]) == world
+        print(json.dumps({"metric": "mel_frames_per_sec", "value": round(red["frames"] / red["seconds"], 2),
+                          "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(red["seconds"] / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "stub",
+                          "config": {"workload": "STUB (no GPU work): rank launch + partition + reductions only"},
+                          "world_size": red["world_size"], "backend": red["backend"],
+                          "per_rank_frames": [int(x) for x in red["per_rank_frames"]],
+                          "per_rank_seconds": [round(x, 4) for x in red["per_rank_seconds"]], "scaling_c4": c4}), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside torch.distributed.run: N ranks as a CHILD process (never an exec: this may run under a
+    profiler whose preloaded library has already initialised the GPU), one rank per GPU, rendezvous on 127.0.0.1.  The
+    child's rank 0 prints the one JSON line; it is relayed as this process's stdout, stderr passes through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what this pool's driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"--gpus {n}: launching {n} ranks: {' '.join(cmd[1:8])} ...")
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in pr.stdout.splitlines():
+        if ln not in lines and ln.strip():
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if pr.returncode == 0 and not lines:
+        raise SystemExit("bench: the ranks exited without printing a result line")
+    raise SystemExit(pr.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--c4-total", type=int, default=256,
+                    help="utterances of the fixed-total C4 leg (`scaling_c4`: strong scaling on BASELINE's scaling "
+                         "config, NFE 16, LPT-split over the ranks); 0 skips it")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY (tests/test_host_cpu.py): no GPU, gloo instead of RCCL, a pass is a 2 ms sleep; the "
+                         "line says data = stub.  Exercises the rank launch, partition and reductions on CPU")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,13 +225,24 @@ def main():
     if args.workload in ("C4", "C5"):
         args.no_roofline = True   # the in-situ GEMM timing is set up for the v1_Base shapes of C2 / C3
 
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])           # does not return; nothing has touched the GPU yet
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torch.distributed.run: always RCCL
+    if args.stub:
+        return stub_main(args, rank, world, distributed)
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     # host-side prep (seeded noise, masks, token ids) is a few tiny CPU ops per pass: keep every rank on a small, fixed
     # number of threads so 8 ranks on one node do not oversubscribe the host with OpenMP teams
@@ -263,6 +386,20 @@ def main():
     rank_frames, rank_seconds = [int(x) for x in red["per_rank_frames"]], red["per_rank_seconds"]
     gen_audio_s = gen_frames * 256 / 24000.0
     value = frames / elapsed
+    assert red["world_size"] == world and len(rank_frames) == world, (red["world_size"], world, rank_frames)
+
+    scaling_c4 = None
+    if args.workload == "C2" and args.c4_total > 0 and not args.eager:
+        def run_utt(x):
+            w, ids, r, t = x
+            mel, _ = cfm.sample(w, ids, duration=t, steps=16, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+            return voc.decode(mel[:, r:t, :].permute(0, 2, 1))
+
+        scaling_c4 = c4_fixed_total(args.c4_total, rank, world, dist if distributed else None,
+                                    lambda r, t: (SY.synthetic_ref_wave(r).cuda(), SY.synthetic_text_ids(t), r, t),
+                                    run_utt, torch.cuda.synchronize, "cuda")
+        log(f"scaling_c4: {scaling_c4['utterances']} utterances over {world} rank(s): "
+            f"{scaling_c4['mel_frames_per_sec']} mel-frames/s in {scaling_c4['seconds']} s")
 
     OPS = (("QKV", OP_QKV), ("ATTN", OP_ATTN), ("OUT", OP_OUT), ("FF1", OP_FF1), ("FF2", OP_FF2))
     KERNEL_OF = {"QKV": "gemm_bf16*<EPI_QKV_ROPE>", "OUT": "gemm_bf16*<EPI_GATE_RES>", "FF1": "gemm_bf16*<EPI_BF16_GELU>",
@@ -344,8 +481,11 @@ def main():
         wav3 = SY.synthetic_ref_wave(R3, batch=B3).cuda()
         text3 = SY.synthetic_text_ids(N3, batch=B3)
 
+        c3_mel = [None]
+
         def c3_pass():
             mel, _ = cfm.sample(wav3, text3, duration=N3, steps=NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, seed=0)
+            c3_mel[0] = mel
             return voc.decode(mel[:, R3:, :].permute(0, 2, 1))
 
         c3_pass()
@@ -354,6 +494,18 @@ def main():
         c3_pass()
         torch.cuda.synchronize()
         c3_s = time.perf_counter() - c0
+        # self-certification of the timed pass: items of the batch-32 result (256 x 256 ping-pong GEMMs, LDS attention,
+        # separate LayerNorms) against the SAME items sampled alone at NFE 32 (64 x 64 GEMMs, fused AdaLN) -- a
+        # size-independent property; the oracle leg of this comparison lives in tests/test_baseline_configs_gpu.py
+        mel_b = c3_mel[0].detach().clone()
+        c3_par = {}
+        for it in (0, 31):
+            one, _ = cfm.sample(wav3[it:it + 1], text3[it:it + 1], duration=N3, steps=NFE, cfg_strength=CFG,
+                                sway_sampling_coef=SWAY, seed=0)
+            c3_par[it] = float((mel_b[it, R3:] - one[0, R3:]).norm() / one[0, R3:].norm())
+        del mel_b
+        if max(c3_par.values()) > 1e-2:
+            raise SystemExit(f"bench: C3 batch-32 items differ from their batch-1 runs: {c3_par}")
         # one more pass with rocm-smi sampled in the middle of it: the large-M kernels run at the board's power cap, so the
         # clock they sustain -- not 2.4 GHz -- bounds what fraction of the 2.5 PFLOP/s peak is reachable
         power = {}
@@ -389,6 +541,10 @@ def main():
         gem3 = [k for k in per3 if k != "ATTN"]
         roofline_c3 = {"workload": f"C3: batch {B3}, N_ref={R3} N={N3}, NFE={NFE}, CFG batched ({2 * B3 * N3} rows per launch)",
                        "mel_frames_per_sec": round(B3 * N3 / c3_s, 1), "pass_ms": round(c3_s * 1e3, 1),
+                       "parity_vs_batch1_rel_l2": round(max(c3_par.values()), 6),
+                       "parity_vs_batch1": {"items": {str(k): round(v, 6) for k, v in c3_par.items()}, "nfe": NFE,
+                                            "tolerance_rel_l2": 1e-2,
+                                            "against": "the same items sampled at batch 1 (generated frames of the final mel)"},
                        "peak_tflops": PEAK_BF16_TFLOPS,
                        "ops": {k: {"us": v["us"], "tflops": v["tflops"], "frac": v["frac"], "launches": v["launches"]}
                                for k, v in per3.items()},
@@ -465,6 +621,8 @@ def main():
         if parity is not None:
             line["parity_rel_l2"] = round(parity["rel_l2_generated"], 6)
             line["parity"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
+        if scaling_c4 is not None:
+            line["scaling_c4"] = scaling_c4
         if concurrent is not None:
             line["concurrent"] = concurrent
         if roofline is not None:
@@ -477,6 +635,7 @@ def main():
     if parity is not None and parity["rel_l2_generated"] > parity["tolerance_rel_l2"]:
         raise SystemExit(f"bench: GPU mel differs from the oracle: rel L2 {parity['rel_l2_generated']:.3e}")
     if distributed:
+        dist.barrier()      # rank 0's roofline legs run while the others wait here, not inside a torn-down group
         dist.destroy_process_group()
 
 

@@ -8,6 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # F5E_HIP_LIB: diagnostics only (tools/convpos_time.py loads the -DF5E_TOOLS build); the product loads the in-tree library
 LIB_PATH = os.environ.get("F5E_HIP_LIB") or os.path.join(_HERE, "libf5e_hip.so")
 
+ABI_VERSION = 2   # F5E_ABI_VERSION of include/f5e_abi.h
+
 ACT_NONE, ACT_SILU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_MISH = range(6)
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -23,7 +25,6 @@ SIGNATURES = {
     "f5e_gemm_bf16_bias_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "f5e_gemm_bf16_gate_residual_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "f5e_gemm_bf16_qkv_rope_ln": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
-    "f5e_ln_finalize": [_P, _P, _I, _I, _F, _I, _P],
     "f5e_adaln_pre": [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I],
     "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
@@ -76,7 +77,7 @@ class LnFuse(C.Structure):
     """f5e_ln_fuse: one side (consumer: stats..eps, producer: xs_out..stats_out) is filled per launch."""
     _fields_ = [("stats", _P), ("parts", _I), ("c", _P), ("d", _P), ("cd_stride", _I), ("cd_rows", _I),
                 ("cd_eval_stride", _I), ("eval_ptr", _P), ("rows_per_seq", _I), ("eps", _F),
-                ("xs_out", _P), ("ld_xs", _I), ("next_scale", _P), ("stats_out", _P), ("row_stats", _P)]
+                ("xs_out", _P), ("ld_xs", _I), ("next_scale", _P), ("stats_out", _P)]
 
 
 class DitPlan(C.Structure):
@@ -90,12 +91,10 @@ class DitPlan(C.Structure):
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
         + [("timer", _P), ("timer_op", _I)]
         + [("fuse_ln", _I), ("ln_stats", _P), ("cd", _P), ("cd_stride", _I)]
-        + [("ln_rowstats", _P)]
         + [("mall_prefetch", _I)]
     )
 
-WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp",
-            "ln_rowstats")
+WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp")
 
 
 class DitWorkspace(C.Structure):
@@ -124,8 +123,8 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch, also loud
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, C.c_int)
-        if handle.f5e_abi_version() != 1:
-            raise RuntimeError(f"libf5e_hip ABI version {handle.f5e_abi_version()} != 1")
+        if handle.f5e_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libf5e_hip ABI version {handle.f5e_abi_version()} != {ABI_VERSION}")
         _lib = handle
     return _lib
 

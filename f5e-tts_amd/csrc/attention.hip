@@ -21,7 +21,6 @@
 // batch 1 (N = 469: 15 q-tiles x 32 (s, head) x 4 splits = 1920 waves).
 //   S^T = K . Q^T  (lane-local softmax statistics),  O^T = V^T . P^T with P taken from the S^T accumulator registers
 //   (cdna guide section 3 "An accumulator tile as the next MFMA's operand").
-#include <cstdlib>
 #include "f5e_common.h"
 
 namespace {
@@ -256,8 +255,10 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
 // memory (K: 2 x 4 KiB, V: 2 x 4 KiB per 64 keys), so the DMA is a linear copy and a fragment read is
 // ds_read_b128 at fragment*1 KiB + (lane&31)*32 + (lane>>5)*16 (2-way bank conflict, LDS is far from saturated).
 // NST = ring depth (48 / 32 KiB of LDS -> 3 / 5 workgroups per CU by LDS), OCC = waves per SIMD the register allocation must
-// leave room for (__launch_bounds__ second argument: 4 -> <= 128 VGPRs, 5 -> <= 96).
-template <int NST, int OCC, int MS = 0>   // MS = 1: row sums on the matrix pipe (experiment, F5E_ATTN_VARIANT=5; see below)
+// leave room for (__launch_bounds__ second argument: 4 -> <= 128 VGPRs, 5 -> <= 96).  Shipped: <2, 4> (C3, us per launch: 3
+// stages -> 3 workgroups per CU 324; 2 stages -> 4 per CU, VGPR-limited, 292; forcing 5 per CU with 3 spills 300; row sums
+// on the matrix pipe through an all-ones A operand 293 vs 287 and the GEMMs behind it 1-2 % slower under the power cap).
+template <int NST, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   constexpr int TILE_BYTES = 16384;  // K 8 KiB + V 8 KiB per 64 keys
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,18 +309,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   f32x16 oacc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-  // MS = 1, row sums on the matrix pipe: the kernel is VALU-bound by instruction count (per 64-key tile and wave 32
-  // quarter-rate v_exp = 512 cycles, as many as all 16 MFMAs, plus ~100 other VALU instructions) and the matrix pipe has
-  // slack, so an all-ones A operand turns l += sum_keys p into four more MFMAs per tile (every row of the result is the
-  // column sum, lane-local for the lane's query) instead of 32 v_add + a cross-half add.  Measured at C3, same box, two runs
-  // each: 293 us with it, 287 us without -- and the GEMMs that follow run 1-2 % slower too: the chip is power-capped
-  // (DESIGN 4), four MFMAs cost more energy than the adds they replace.  Off.
-  f32x16 lacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
   float m_run = -INFINITY, l_val = 0.f;
 
   if (ntiles > 0) stage(0, 0);
@@ -368,8 +357,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
     if (__builtin_amdgcn_ballot_w64(jump) != 0) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2(m_run - m_new);
-      if (MS) lacc[0] *= alpha;   // the other 15 registers of the sum tile are copies nobody reads (bounded: sums of p <= 2^8)
-      else l_val *= alpha;
+      l_val *= alpha;
       m_run = m_new;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
@@ -378,7 +366,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[t][r] = fast_exp2(__builtin_fmaf(st[t][r], a.scale_log2e, -m_run));
-    if (!MS) {
+    {
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -393,7 +381,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[t][8 * s + j];
-        if (MS) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           // V fragment (tile t, s16 = s, dt): index ((t*2 + s)*2 + dt), each 1 KiB, lane-linear
@@ -407,7 +394,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
 
   const int q_row = (qb * 4 + wave) * 32 + ql;
   if (q_row < a.rows_per_seq) {
-    const float l_run = MS ? lacc[0] : l_val;
+    const float l_run = l_val;
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     bf16* op = a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + 4 * hh;
 #pragma unroll
@@ -439,14 +426,7 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
   // LDS-free kernel would already have >= 8 waves per CU without any KV split)
   if (splits == -1 || (splits == 0 && grid >= 8192)) {
     const int g128 = ((rows_per_seq + 127) / 128) * H * S;
-    // Ring depth / occupancy (C3, us per launch): 3 stages = 48 KiB -> 3 workgroups per CU 324; 2 stages = 32 KiB -> 4 per CU
-    // (VGPR-limited) 292; forcing 5 per CU (<= 96 VGPRs, 3 spilled) 300.  The softmax is VALU-bound: more resident waves
-    // beat a deeper prefetch.  F5E_ATTN_VARIANT=3 restores the 3-stage ring (A/B switch).
-    static const int variant = getenv("F5E_ATTN_VARIANT") ? atoi(getenv("F5E_ATTN_VARIANT")) : 1;
-    if (variant == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 5>), dim3(g128), dim3(256), 2 * 16384, st, a);
-    else if (variant == 3) hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 4>), dim3(g128), dim3(256), 3 * 16384, st, a);
-    else if (variant == 5) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4, 1>), dim3(g128), dim3(256), 2 * 16384, st, a);
-    else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
+    hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
     F5E_LAUNCH_CHECK("flash_attn_lds");
     return F5E_OK;
   }

@@ -476,7 +476,11 @@ static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_
   // Two kernels, same arithmetic up to the order of the fp32 partial sums: grids that fit the chip in one round (one
   // workgroup per CU, e.g. batch 1 with CFG: 256 workgroups) are bound by weight delivery and LDS reads -> split-tap
   // kernel (140 KB LDS); larger grids take the output-split ring (44 KB LDS, 3 workgroups per CU overlap each other).
-  static const int forced = getenv("F5E_CONVPOS") ? atoi(getenv("F5E_CONVPOS")) : 0;  // diagnostics: 1 split, 2 ring
+#ifdef F5E_TOOLS
+  static const int forced = getenv("F5E_CONVPOS") ? atoi(getenv("F5E_CONVPOS")) : 0;  // tools build: 1 split, 2 ring
+#else
+  constexpr int forced = 0;
+#endif
   const int n_cu = f5e_cu_count();
   const bool split = forced ? forced == 1 : (size_t)groups * a.tiles_t * S <= (size_t)n_cu;
   if (fused) *fused = false;

@@ -14,7 +14,6 @@
 //     The LDS image is lane-linear; the bank swizzle (16-B chunk ^ ((row>>1)&7)) is applied to the
 //     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
 //     16-lane ds_read_b128 groups are conflict free.
-#include <cstdlib>
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
 
@@ -41,22 +40,16 @@ __device__ __forceinline__ void wait_stages(int nst) {
   }
 }
 
-// BK = K-step: 64 (128-byte LDS rows, two rows per 256-byte bank line: swizzle (row >> 1) & 7) or 128 (256-byte rows = one
-// bank line each: swizzle row & 15; kept as a tuning parameter, no shipped instantiation uses it -- see dispatch()).
-//
-// SK = 2 (intra-workgroup split-K, gate+residual launches with at most one workgroup per CU): a second group of WGM x WGN
-// waves runs the upper half of K through its own LDS ring, the two accumulator sets meet in LDS in a fixed order (group 0 +
-// group 1: deterministic, unlike atomics) and group 0 runs the epilogue.  Why: at M = 938 the out-projection and FF2 are 240
-// tiles on 256 CUs, and what a lone 4-wave workgroup draws through its LDS-DMA ring (32 GB/s at FF2) is bounded by the
-// bytes it keeps in flight over the load latency, not by the CU: FF1, with two workgroups per CU, moves 48 GB/s per CU.
-// Opt-in (see dispatch()): it pays with HBM-resident weights, not behind the Infinity-Cache prefetch of the block chain.
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int BK = 64, int SK = 1>
-__global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs a) {
+// K-step 64: 128-byte LDS rows, two rows per 256-byte bank line, swizzle (row >> 1) & 7.  (Measured and dropped, DESIGN 4:
+// K-step 128, 5-8 stage rings, 8 waves on the 64x64 tile, intra-workgroup split-K for the one-workgroup-per-CU launches.)
+// DBG == 3: in-kernel timestamps for tools/gemm_trace.hip (never instantiated by the library).
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr int BK = 64;
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                   // bytes per LDS row
-  auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (row & 15); };
-  constexpr int NT = 64 * WGM * WGN;  // threads of one K group: WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
-  static_assert(SK == 1 || (SK == 2 && EPI == EPI_GATE_RES && FUSE != 1 && DBG == 0), "split-K: gate+residual launches only");
+  auto swz = [](int row) { return (row >> 1) & 7; };
+  constexpr int NT = 64 * WGM * WGN;  // WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -65,10 +58,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = SK == 1 ? 0 : wave_all / (WGM * WGN);   // K group (wave-uniform)
-  const int wave = SK == 1 ? wave_all : wave_all % (WGM * WGN);
-  const int tid = SK == 1 ? (int)threadIdx.x : (int)threadIdx.x % NT;   // thread index inside the K group
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = (int)threadIdx.x;
   unsigned long long* trc = nullptr;
   if constexpr (DBG == 3) {
     trc = a.trace + (size_t)blockIdx.x * 48;
@@ -87,7 +78,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
   if (NT == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
-    if (grp == 0) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
+    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
     return;
   }
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
@@ -115,7 +106,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
   constexpr int A_IT = BM * CPR / NT;
   constexpr int W_IT = BN * CPR / NT;
   static_assert(A_IT >= 1 && W_IT >= 1 && A_IT * NT == BM * CPR && W_IT * NT == BN * CPR, "tile / thread-count mismatch");
-  static_assert(BK == 64 || BK == 128, "K-step 64 or 128");
   const bf16* a_src[A_IT];
   const bf16* w_src[W_IT];
 #pragma unroll
@@ -132,15 +122,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
     const int gr = min(n0 + row, a.N - 1);
     w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
   }
-  const int KT = a.K / (BK * SK);       // K-steps of this group; group g owns K-tiles [g KT, (g + 1) KT)
-  char* const ring = smem + grp * (NSTAGE * STAGE);
-  const int k_first = grp * KT * BK;
+  const int KT = a.K / BK;
+  char* const ring = smem;
   auto stage = [&](int buf, int kt) {
     char* base = ring + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + k_first + kt * BK, base + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + k_first + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
   };
 
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
@@ -249,11 +238,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
     else wait_stages<LPT, 0>(nst);
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
     if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
-    if (DBG != 2 && kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
+    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
     const char* As = ring + buf * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < (DBG == 1 ? 0 : BK / 32); ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 xf[TM], wf[TN];
       const int c = kk * 4 + fq;
 #pragma unroll
@@ -277,25 +266,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
   }
 
   if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
-  float* fuse_lds = (float*)(smem + SK * NSTAGE * STAGE);  // 1 KiB behind the ring(s) (FUSE != 0 launches only)
-  if constexpr (SK == 2) {
-    // the two K halves meet in LDS (group 0's ring, idle now): 4 KiB per wave, lane-linear 16-byte slots
-    __builtin_amdgcn_s_barrier();  // every wave is past its last ds_read of the rings
-    char* xch = smem + wave * (TM * TN * 1024) + lane * 16;
-    if (grp == 1) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) *(f32x4*)(xch + (i * TM + j) * 1024) = acc[i][j];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) return;  // a wave that has ended no longer counts at the workgroup's later barriers
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] += *(const f32x4*)(xch + (i * TM + j) * 1024);
-  }
+  float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // 1 KiB behind the ring (FUSE != 0 launches only)
   if (FUSE == 1) {
     // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
     // M2 = sum_p M2_p + 64 sum_p (mean_p - mean)^2, rstd = rsqrt(M2 / K + eps)
@@ -495,9 +466,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * SK) void gemm_bf16_kernel(GemmArgs
   }
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int BK = 64, int SK = 1>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0>
 int launch(GemmArgs& a, hipStream_t st) {
-  F5E_REQUIRE(a.K % (BK * SK) == 0, "gemm_bf16: K=%d is not a multiple of %d (split-K %d)", a.K, BK * SK, SK);
+  constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.m_major = a.M > a.N;
@@ -507,58 +478,28 @@ int launch(GemmArgs& a, hipStream_t st) {
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
   const int grid = a.n_main + ((WGM * WGN == 4 && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
   if (grid == a.n_main) a.pf = F5ePrefetch{};
-  constexpr int lds = SK * NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
+  constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK, SK>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, BK, SK>), dim3(grid), dim3(64 * WGM * WGN * SK), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
 
-template <int EPI, int DBG>
-int launch_dbg(GemmArgs& a, hipStream_t st) {
-  a.tiles_m = (a.M + 63) / 64;
-  a.tiles_n = (a.N + 63) / 64;
-  a.m_major = 0;
-  a.tile_magic = div_magic_of(a.tiles_m);
-  a.rps_magic = div_magic_of(a.rows_per_seq);
-  a.n_main = a.tiles_m * a.tiles_n;
-  a.pf = F5ePrefetch{};
-  hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, EPI, 3, DBG>), dim3(a.tiles_m * a.tiles_n), dim3(256), 3 * 128 * 128, st, a);
-  F5E_LAUNCH_CHECK("gemm_bf16_dbg");
-  return F5E_OK;
-}
-
-// tile_hint: 0 = auto; otherwise tile + 10 * stages with tile 1 = 128x128, 2 = 128x64, 3 = 64x64 and stages in
-// {0 (default for the tile), 2, 3, 4} (64x64 also 5, 6, 8).
+// tile_hint: 0 = auto; 1 = 128x128 (8 waves, 2 stages), 2 = 128x64 (3 stages), 3 = 64x64 (3 stages; 4 for a one-round grid
+// with K >= 2048), 9 = the 256x256 ping-pong kernel of gemm_bf16_pp.hip (what auto picks at large M).  One code path per
+// tile family: the tuning variants that were measured and lost (deeper rings, other wave grids, split-K) are in DESIGN 4.
 template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int sel = tile_hint % 10, ns = tile_hint / 10;
-  if (a.ln_stats || a.stats_out) {  // fused AdaLN: 64x64 tiles (small M) or the 256x256 ping-pong kernel (large M)
+  int sel = tile_hint;
+  F5E_REQUIRE(sel == 0 || sel == 1 || sel == 2 || sel == 3 || sel == 9, "gemm_bf16: unknown tile_hint %d (0, 1, 2, 3 or 9)", tile_hint);
+  if (a.ln_stats || a.stats_out) {  // fused AdaLN: the 64x64 tile family (f5e_ln_fuse; small row counts)
     F5E_REQUIRE(!(a.ln_stats && a.stats_out), "gemm_bf16: a launch is an AdaLN consumer or a producer, not both");
     F5E_REQUIRE(!(EPI == EPI_QKV_ROPE && a.qn_w), "gemm_bf16: fused AdaLN and qk_norm need different tiles");
-    if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, 0);
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
-      // (K-step 128 -- template parameter BK -- was measured here for the one-workgroup-per-CU launches: out-projection /
-      // FF2 12.8 / 17.0 us with BK 64, 13.6 / 17.8 with BK 128 x 3 stages, 12.8 / 16.9 with BK 128 x 2 stages: the lone
-      // workgroup's K loop is bound by the ~65 GB/s a CU's LDS-DMA path delivers, not by the number of steps.)
-      if (sel == 5) {  // intra-workgroup split-K (hint 5 + 10 * stages)
-        if (ns == 4) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 64, 2>(a, st);
-        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 64, 2>(a, st);
-      }
-      // Intra-workgroup split-K is OFF by default (F5E_SPLITK=1 / hints 35, 45 switch it on).  Stand-alone with weights
-      // streaming from HBM it wins (tools/gemm_tune.py at M = 938: out-projection 10.4 -> 9.8 us, FF2 12.3 -> 11.0), but in
-      // the block chain, where the weights were prefetched into the Infinity Cache and the launch also hosts prefetch
-      // workgroups, it loses: C2 47.7 vs 46.0 ms per pass (same box, two runs each; out-projection 13.7 vs 12.6 us, FF2 17.5
-      // vs 16.7 with launch gaps).
-      static const int splitk = getenv("F5E_SPLITK") ? atoi(getenv("F5E_SPLITK")) : 0;
-      if (splitk && sel == 0 && blocks(64, 64) <= 256 && a.K >= 1024 && a.K % 128 == 0) {
-        if (a.K >= 2048) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 64, 2>(a, st);
-        return launch<64, 64, EPI, 3, 2, 2, 0, 2, 64, 2>(a, st);
-      }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
@@ -566,52 +507,25 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
     }
   }
-  // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip); hint 9 forces it (tests / tuning).  Crossover against the
-  // 128x128 ring kernel measured on the four DiT shapes (tools/gemm_tune.py M 21,9): M = 7.5k ring kernel ahead by 0-40 %,
-  // M = 13k ping-pong ahead by 5-18 %, M = 30k by 8-37 %: it takes over at 44 row tiles of 256, whatever N.
-  if (sel == 9 || (tile_hint == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st, sel == 9 ? ns : 0);
-  if constexpr (EPI == EPI_GATE_RES) {
-    if (sel == 5) {  // intra-workgroup split-K (hint 5 + 10 * stages)
-      if (ns == 4) return launch<64, 64, EPI, 4, 2, 2, 0, 0, 64, 2>(a, st);
-      return launch<64, 64, EPI, 3, 2, 2, 0, 0, 64, 2>(a, st);
-    }
-  }
+  // large M: the 256x256 ping-pong kernel (gemm_bf16_pp.hip).  Crossover against the 128x128 ring kernel measured on the
+  // four DiT shapes: M = 7.5k ring kernel ahead by 0-40 %, M = 13k ping-pong ahead by 5-18 %, M = 30k by 8-37 %: it takes
+  // over at 44 row tiles of 256, whatever N.
+  if (sel == 9 || (sel == 0 && uses_pp(a.M, a.K))) return launch_pp(EPI, a, st);
   if (EPI == EPI_QKV_ROPE && a.qn_w) sel = 1;  // qk_norm reduces over a head inside one wave: 128-wide tiles only
-  if (sel <= 0) {
-    // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M, and
-    // tools/gemm_tune.py on MI355X has 64x64 / 3 stages fastest for every DiT shape at M = 938
+  if (sel == 0) {
+    // the largest tile that still gives ~2 blocks per CU (256 CUs): these GEMMs are latency-bound at small M (64x64 with
+    // 3 stages is fastest for every DiT shape at M = 938)
     if (blocks(128, 128) >= 320) sel = 1;  // 8-wave 128x128: ahead of the smaller tiles from ~1.3 workgroups per CU on
     else if (blocks(128, 64) >= 512) sel = 2;
     else sel = 3;
   }
-  // stages: 128x128 wants 2 (64 KiB LDS -> 2 workgroups per CU; measured 386 vs 556 us at M = 60k), small tiles 3
-  // 64x64 with one workgroup per CU and a long K (FF2: K = 2048, weights streaming from HBM): a 4th stage hides the
-  // HBM latency (15.5 -> 12.9 us at M = 938 with HBM-resident weights); at K = 1024 or 3 workgroups per CU it does not pay
-  if (ns == 0) ns = (sel == 1) ? 2 : ((sel == 3 && a.K >= 2048 && blocks(64, 64) <= 256) ? 4 : 3);
-  switch (sel * 10 + ns) {
-    // 128x128: 8 waves (4 x 2, 32 x 64 per wave), 2 workgroups per CU = 16 waves per CU to cover the per-K-step
-    // waits; measured at M = 60k (rocprofv3): QKV 564 vs 710 us, gated residual 324 vs 381, FF1 363 vs 377 for the
-    // 4-wave 2 x 2 grid.  (256-wide tiles and 3 stages were slower.)
-    case 12: return launch<128, 128, EPI, 2, 4, 2>(a, st);
-    case 42: return launch<128, 128, EPI, 2, 2, 2>(a, st);   // 4 waves, 64 x 64 per wave (tuning reference)
-    case 83: return launch<128, 128, EPI, 3, 4, 2>(a, st);   // experiments: deeper rings / bigger tiles, 1 workgroup per CU
-    case 84: return launch<128, 128, EPI, 4, 4, 2>(a, st);
-    case 13: return launch<128, 128, EPI, 3>(a, st);
-    case 22: return launch<128, 64, EPI, 2>(a, st);
-    case 23: return launch<128, 64, EPI, 3>(a, st);
-    case 24: return launch<128, 64, EPI, 4>(a, st);
-    case 32: return launch<64, 64, EPI, 2>(a, st);
-    case 33: return launch<64, 64, EPI, 3>(a, st);
-    case 34: return launch<64, 64, EPI, 4>(a, st);
-    case 35: return launch<64, 64, EPI, 5>(a, st);
-    case 36: return launch<64, 64, EPI, 6>(a, st);
-    case 38: return launch<64, 64, EPI, 8>(a, st);
-    case 39: return launch_dbg<EPI, 1>(a, st);   // ablation: LDS-DMA ring + barriers only (results are garbage)
-    case 37: return launch_dbg<EPI, 2>(a, st);   // ablation: ds_read + MFMA + barriers only
-    default:
-      f5e_set_error("gemm_bf16: unknown tile_hint %d", tile_hint);
-      return F5E_ERR_BAD_SHAPE;
-  }
+  // 128x128: 8 waves (4 x 2, 32 x 64 per wave), 2 stages = 64 KiB of LDS -> 2 workgroups per CU = 16 waves per CU to
+  // cover the per-K-step waits.  64x64 with one workgroup per CU and a long K (FF2: K = 2048, weights streaming from
+  // HBM): a 4th stage hides the HBM latency (15.5 -> 12.9 us at M = 938); at K = 1024 or 3 workgroups per CU it does not.
+  if (sel == 1) return launch<128, 128, EPI, 2, 4, 2>(a, st);
+  if (sel == 2) return launch<128, 64, EPI, 3>(a, st);
+  if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4>(a, st);
+  return launch<64, 64, EPI, 3>(a, st);
 }
 
 int check_common(const GemmArgs& a) {
@@ -633,7 +547,6 @@ int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
   a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;
   a.cd_rows = ln->cd_rows; a.cd_eval_stride = ln->cd_eval_stride; a.ln_eps = ln->eps;
   a.eval_ptr = ln->eval_ptr;
-  a.ln_rowstats = ln->row_stats;
   if (a.rows_per_seq <= 0) a.rows_per_seq = ln->rows_per_seq;
   return F5E_OK;
 }

@@ -33,17 +33,15 @@ struct GemmArgs {
   int n_pad; int heads; int rope_heads;
   const float* cos_sin;  // [rows_per_seq][32][2]
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
-  unsigned long long* trace;  // DBG == 3 only (tools/gemm_trace.hip): per-workgroup timeline, 48 slots
+  unsigned long long* trace;  // diagnostics builds only (tools/gemm_trace.hip, tools/pp_timeline.py): per-workgroup timeline
   // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
   //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
   //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - mean c[n]) + d[n]
   //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
   //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
   const float* ln_stats; int ln_parts;
-  const float* ln_rowstats;   // large-M consumer (gemm_bf16_pp.hip): [M + 1][2] = (mean, rstd) from f5e_ln_finalize
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
-  int pp_stagger;  // gemm_bf16_pp.hip: delayed start of the workgroups that own one tile fewer
   int pp_ngroup;   // gemm_bf16_pp.hip: n-tiles per column group of the tile order (0 = plain m-major)
   F5ePrefetch pf;  // weights of the next kernels, pulled into the Infinity Cache by grid-tail workgroups (small M only)
 };
@@ -71,7 +69,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 
 
 // gemm_bf16_pp.hip: 256x256 tile, 8 waves in two staggered groups (defined there; epi = EPI_* id)
-int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg = 0);  // dbg 1..3: timing ablations (garbage results)
+int launch_pp(int epi, GemmArgs& a, hipStream_t st);
 // the rule both the dispatcher and f5e_dit_forward use: launches of this many rows take the 256x256 kernel
 inline bool uses_pp(int M, int K) { return K >= 128 && (M + 255) / 256 >= 44; }
 

@@ -49,11 +49,9 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Epilogue shared by the two tile schedules (pp_tile: 8 waves, 256 x 256; pp2_tile: 4 waves, 256 x 128).  A wave owns the
-// 128 x 64 sub-tile at rows m0 + 128 wr, columns n0 + 64 wc, accumulators acc[4][8] in the swapped-operand layout, and
-// 16 KiB of the (now idle) LDS ring at smem + wave * 16 KiB as staging space.  LNB = byte offset of the fused-AdaLN
-// consumer's operands behind the ring (FUSE == 1).
-template <int EPI, int DBG, int FUSE, int LNB>
+// Epilogue of a tile.  A wave owns the 128 x 64 sub-tile at rows m0 + 128 wr, columns n0 + 64 wc, accumulators acc[4][8]
+// in the swapped-operand layout, and 16 KiB of the (now idle) LDS ring at smem + wave * 16 KiB as staging space.
+template <int EPI>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4 (&acc)[4][8], int wave, int lane, int wr,
                                             int wc, int m0, int n0) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -64,23 +62,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
   // complete here: the balancing barrier above is the last barrier instance of both groups.
   char* reg = smem + wave * 16384;
   const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
-  if constexpr (FUSE == 1) {
-    // (mean, rstd) of the tile's 256 rows and c / d of its 256 columns were LDS-DMA'd into the 4 KiB behind the ring at
-    // the top of this tile (below): no memory round trip here.  The accumulators are normalised in place, so every
-    // epilogue that follows runs unchanged with bias = NULL (d carries it).
-    const float* lnb = (const float*)(smem + LNB);
-    // column block outermost: only one (c, d) quad pair is live beside the 128 accumulator registers
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 cq = *(const f32x4*)(lnb + 512 + wc * 64 + i * 16 + fq * 4);
-      const f32x4 dq = *(const f32x4*)(lnb + 768 + wc * 64 + i * 16 + fq * 4);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x2 st = *(const f32x2*)(lnb + (wr * 128 + j * 16 + fr) * 2);
-        acc[i][j] = st[1] * acc[i][j] + ((-st[0] * st[1]) * cq + dq);
-      }
-    }
-  }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
     if (a.N % 8 == 0 && a.ldo % 8 == 0) {
       f32x4 bq[4];
@@ -107,13 +88,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
         const int r = it * 8 + (lane >> 3);
         const int m = mbase + r, n = nbase + c * 8;
         const uint4 v = *(const uint4*)(reg + r * 128 + ((c ^ (r & 7)) << 4));
-        if (DBG == 6) { if (v.x == 0x7fc1u && m < 0) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v; }  // no stores
-        else if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)(DBG == 10 ? (m & 4095) : m) * a.ldo + n) = v;
+        if (m < a.M && n < a.N) *(uint4*)((bf16*)a.out + (size_t)m * a.ldo + n) = v;
       }
       return;
     }
   }
-  if constexpr (EPI == EPI_GATE_RES && FUSE != 1) {
+  if constexpr (EPI == EPI_GATE_RES) {
     // Lean read-modify-write for the common wave tile: all 128 rows inside [0, M) and inside their sequences' lengths, one
     // gate row.  Sequence, position, lengths and gate row are per-wave scalars (the wave's rows touch at most two sequences
     // when rows_per_seq >= 128), so the per-row division / modulo / loop / predicate of the general path below (~3000
@@ -135,8 +115,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
         const int c = lane & 15, rq = lane >> 4;
         const f32x4 ga = *(const f32x4*)(a.gate + eoff + (size_t)grow_a * a.gate_stride + nbase + c * 4);
         const f32x4 bc = a.bias ? *(const f32x4*)(a.bias + nbase + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 nsq = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (FUSE == 2) nsq = *(const f32x4*)(a.next_scale + eoff + nbase + c * 4) + 1.0f;  // gate_rows == 1
         // uniform base + 32-bit byte offset per row (a 128-row tile of fp32 spans < 2^31 bytes).  The row stride is made
         // opaque per tile: otherwise the row offsets are hoisted out of the persistent tile loop as loop invariants, live
         // (and spilled) across the K loop
@@ -165,24 +143,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
             const f32x4 v = *(const f32x4*)(reg + ((rd0 ^ ((b & 3) << 6)) + b * 1024));
             const f32x4 xn = xv[b] + ga * (v + bc);
             *(f32x4*)(xbase + (off0 + (unsigned)(half * 64 + b * 4) * rstride)) = xn;
-            if constexpr (FUSE == 2) {
-              // AdaLN producer (same contract as the general path below): xs for the next linear and (mean, M2) of x_new
-              // over this wave's 64 columns; the 16 lanes of a row are one DPP row
-              const int row = mbase + half * 64 + b * 4 + rq;
-              const f32x4 y = xn * nsq;
-              *(bf16x4*)(a.xs_out + (size_t)row * a.ld_xs + nbase + c * 4) = f2bf4(y[0], y[1], y[2], y[3]);
-              float sm = (xn[0] + xn[1]) + (xn[2] + xn[3]);
-              sm = add_xor2(add_xor1(sm));
-              sm += dpp_f32<0x124>(sm);
-              sm += dpp_f32<0x128>(sm);
-              const float mw = sm * (1.0f / 64.0f);
-              const f32x4 dv = xn - mw;
-              float q2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
-              q2 = add_xor2(add_xor1(q2));
-              q2 += dpp_f32<0x124>(q2);
-              q2 += dpp_f32<0x128>(q2);
-              if (c == 0) *(f32x2*)(a.stats_out + ((size_t)row * (a.N >> 6) + (nbase >> 6)) * 2) = f32x2{mw, q2};
-            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the region is overwritten
         }
@@ -200,8 +160,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
         bq[i] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       const int c = lane & 15;
-      f32x4 nsq = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (FUSE == 2) nsq = *(const f32x4*)(a.next_scale + eoff + min(nbase + c * 4, a.N - 4)) + 1.0f;  // gate_rows == 1
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         // 64 rows x 256 B: 16 chunks of 16 B (4 fp32) per row, chunk index XORed with r & 15
@@ -241,30 +199,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
           for (int u = 0; u < 8; ++u) {
             const int r = (b8 * 8 + u) * 4 + (lane >> 4);
             const f32x4 v = *(const f32x4*)(reg + r * 256 + ((c ^ (r & 15)) << 4));
-            f32x4 xn = xv[u];
-            if (inb[u] && ps[u] < len[u]) {
-              xn = xv[u] + gv[u] * v;
-              *(f32x4*)(a.resid + (size_t)(mb + r) * a.ldr + nbase + c * 4) = xn;
-            }
-            if constexpr (FUSE == 2) {
-              // what the NEXT AdaLN needs from x_new (masked rows: the unchanged x): xs for its linear and (mean, M2) over
-              // this wave's 64 columns; the 16 lanes of a row are one DPP row
-              float sm = (xn[0] + xn[1]) + (xn[2] + xn[3]);
-              sm = add_xor2(add_xor1(sm));
-              sm += dpp_f32<0x124>(sm);
-              sm += dpp_f32<0x128>(sm);
-              const float mw = sm * (1.0f / 64.0f);
-              const f32x4 dv = xn - mw;
-              float q2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
-              q2 = add_xor2(add_xor1(q2));
-              q2 += dpp_f32<0x124>(q2);
-              q2 += dpp_f32<0x128>(q2);
-              if (inb[u]) {
-                const f32x4 y = xn * nsq;
-                *(bf16x4*)(a.xs_out + (size_t)(mb + r) * a.ld_xs + nbase + c * 4) = f2bf4(y[0], y[1], y[2], y[3]);
-                if (c == 0) *(f32x2*)(a.stats_out + ((size_t)(mb + r) * (a.N >> 6) + (nbase >> 6)) * 2) = f32x2{mw, q2};
-              }
-            }
+            if (inb[u] && ps[u] < len[u])
+              *(f32x4*)(a.resid + (size_t)(mb + r) * a.ldr + nbase + c * 4) = xv[u] + gv[u] * v;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the region
@@ -431,19 +367,16 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
   gemm_epilogue<EPI, 8, 4>(a, acc, mbase, nbase, lane);
 }
 
-// FUSE: fused AdaLN at large M (same contract as gemm_bf16.hip, f5e_ln_fuse): 1 = consumer (A = xs, epilogue applies
-// rstd (acc - mean c[n]) + d[n] from the per-row tile statistics), 2 = producer (gate+residual epilogue also writes
-// xs = bf16(x_new (1 + next_scale)) and (mean, M2) of x_new per row and 64-column tile).
-template <int EPI, int DBG, int FUSE>  // DBG (timing ablations, results are garbage): 1 no DMA / vmcnt, 2 no ds_read, 3 no MFMA, ...
+// TRACE (tools build only, tools/pp_timeline.py): wall-clock stamps (100 MHz) per workgroup and tile: entry, first K-tile
+// landed (includes the previous tile's store acknowledgements: vmcnt is in order), K loop done, epilogue issued
+template <int EPI, int TRACE>
 __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles, int iter = 0) {
   const int tid = threadIdx.x;
-  // DBG 7 (tools build, tools/pp_timeline.py): wall-clock stamps (100 MHz) per workgroup and tile: entry, first K-tile
-  // landed (includes the previous tile's store acknowledgements: vmcnt is in order), K loop done, epilogue issued
   auto stamp = [&](int k) {
-    if (DBG >= 7 && tid == 0 && a.trace && iter < 16)
+    if (TRACE && tid == 0 && a.trace && iter < 16)
       a.trace[((size_t)blockIdx.x * 16 + iter) * 4 + k] = __builtin_amdgcn_s_memrealtime();
     // shader-clock copies of stamps 1 and 2 behind the table: effective core clock inside the K loop
-    if (DBG >= 7 && tid == 0 && a.trace && iter < 16 && (k == 1 || k == 2))
+    if (TRACE && tid == 0 && a.trace && iter < 16 && (k == 1 || k == 2))
       a.trace[(size_t)gridDim.x * 64 + ((size_t)blockIdx.x * 16 + iter) * 2 + (k - 1)] = __builtin_readcyclecounter();
   };
   stamp(0);
@@ -486,9 +419,8 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int i = tid + 512 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
-    int xa = m0 + (r >> 6) * 128 + (r & 63);
+    const int xa = m0 + (r >> 6) * 128 + (r & 63);
     const int wa = n0 + (r >> 5) * 64 + (r & 31);
-    if (DBG == 9 || DBG == 10) xa &= 4095;  // timing experiment: the A operand from a cache-resident window
     src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
     src[1][j] = a.W + (size_t)min(wa, a.N - 1) * a.ldw + c * 8;       // WH0
     src[2][j] = a.W + (size_t)min(wa + 32, a.N - 1) * a.ldw + c * 8;  // WH1
@@ -515,7 +447,6 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   const int xoff = (wr * 64 + fr) * 128, woff = (wc * 32 + fr) * 128;
   bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
   auto read_x = [&](const char* slot) {
-    if (DBG == 2 || DBG == 4) return;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -523,7 +454,6 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
         xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
   };
   auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
-    if (DBG == 2 || DBG == 4) return;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -534,24 +464,6 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   // prologue: half-tiles 0..4 (K-tile 0 complete + XHa of K-tile 1); the first two must have landed before phase 0
 #pragma unroll
   for (int h = 0; h < 5; ++h) stage(h);   // dispatch guarantees KT >= 2
-  if constexpr (FUSE == 1) {
-    // fused-AdaLN consumer operands, fetched now and used in the epilogue: waves 0-1 the (mean, rstd) pairs of rows
-    // m0 .. m0 + 255 (2 KiB, row_stats has one pad row), wave 2 c[n0 .. n0 + 255], wave 3 d[...] (1 KiB each).  Issued
-    // BEHIND the prologue's half-tiles (in front of them a cold row_stats line delayed the first K-tile by a memory round
-    // trip per tile): one extra operation in the in-order vmcnt queue of waves 0-3.  vmcnt(6) then retires everything up to
-    // half-tile 3's first DMA in phase 0, half-tile 3 in phase 1, half-tile 4 and this operation in phase 2 -- each still
-    // at least one phase before its first read (h2: phase 1, h3: phase 2, h4: phase 4) -- and the window is the usual three
-    // half-tiles from phase 3 on.
-    char* lnb = smem + 8 * HALF_BYTES;
-    if (wave < 2) {
-      const int r = min(m0 + wave * 128 + lane * 2, a.M - 1);
-      glds16(a.ln_rowstats + (size_t)r * 2, lnb + wave * 1024);
-    } else if (wave < 4) {
-      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
-      const int n = min(n0 + lane * 4, a.N - 4);
-      glds16((wave == 2 ? a.ln_c : a.ln_d) + eoff + n, lnb + 2048 + (wave - 2) * 1024);
-    }
-  }
   wait_vm<6>();
   __builtin_amdgcn_s_barrier();
   stamp(1);
@@ -559,7 +471,6 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 
   auto phase_tail = [&](int p) {  // stage half-tile p + 5, then leave only the 3 youngest half-tiles in flight
     const int idx = p + 5;
-    if (DBG == 1 || DBG == 4) return;
     if (idx < TI) stage(idx);
     const int rem = TI - 1 - idx;  // half-tiles still to be staged after this phase
     if (rem >= 0) wait_vm<6>();
@@ -573,7 +484,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kk = 0; kk < ((DBG == 3 || DBG == 4) ? 0 : 2); ++kk)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -606,16 +517,7 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
   stamp(2);
 
-  if (DBG == 5) {  // no epilogue: keep the accumulators alive with a store that never happens
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (s == 1.2345e33f) ((float*)a.out)[tid] = s;
-    return;
-  }
-  pp_epilogue<EPI, DBG, FUSE, 8 * HALF_BYTES>(a, smem, acc, wave, lane, wr, wc, m0, n0);
+  pp_epilogue<EPI>(a, smem, acc, wave, lane, wr, wc, m0, n0);
   stamp(3);
 }
 
@@ -627,16 +529,12 @@ __device__ __forceinline__ void pp_tile(const GemmArgs& a, char* smem, int phys_
 // burst, each waiting for the whole burst to drain (the stores cost 63 of 310 us at C3's FF1, the HBM being idle the
 // rest of the time).  Workgroups that own one tile fewer than the busiest ones (n_tiles % gridDim.x != 0) have a tile time of
 // slack: they start late by an even share of it, which takes the CUs out of phase at no cost in makespan.
-template <int EPI, int DBG = 0, int FUSE = 0>
+template <int EPI, int TRACE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
   const int extra = n_tiles % grid;  // workgroups [0, extra) own one more tile
-  if (a.pp_stagger == 2) {  // experiment: every workgroup, quarter-tile steps
-    const long long slack = (long long)(a.K / 64) * 5000;
-    const int naps = (int)(slack * (((int)blockIdx.x >> 3) & 3) / 4 / 8128);
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-  } else if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
+  if (extra > 0 && (int)blockIdx.x >= extra) {
     // ~5000 cycles per K-tile measured; s_sleep 127 = 8128 cycles
     const long long slack = (long long)(a.K / 64) * 5000;
     const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
@@ -644,461 +542,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs a) {
   }
   int iter = 0;
   for (int p = blockIdx.x; p < n_tiles; p += grid, ++iter) {
-    pp_tile<EPI, DBG, FUSE>(a, smem, p, n_tiles, iter);
+    pp_tile<EPI, TRACE>(a, smem, p, n_tiles, iter);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
     __builtin_amdgcn_s_barrier();
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Second schedule ("pp2"): 4 waves, 256 x 128 tile, 80 KiB of LDS -> TWO workgroups per CU.
-//
-// Why: with one 8-wave workgroup per CU nothing overlaps a tile's epilogue (22-30 % of the GEMM time at C3: the stores
-// run at the HBM roofline while the matrix pipe idles) and the accumulators fill the register file, so the epilogue
-// cannot be software-pipelined into the next tile's K loop.  Two independent workgroups per CU get that overlap from the
-// hardware: each SIMD hosts one wave of each, the matrix pipe serves whichever has MFMAs, and one workgroup's epilogue
-// runs beside the other's K loop (the second half of the grid starts half a tile late).  The price is 1.5x the LDS fill
-// per flop (a 256 x 128 tile loads 48 KiB per K-tile for half the outputs of 64 KiB).
-//
-// Geometry.  wave = wr * 2 + wc owns rows [128 wr, +128) x columns [64 wc, +64): the same 128 x 64 wave tile, fragment
-// reads and quadrant order (A0,B0), (A0,B1), (A1,B1), (A1,B0) as pp_tile.  A K-tile is THREE 16 KiB pieces:
-//     XHa: rows {0..63} of both row halves   W: all 128 columns (per wc: B0 = 32 rows, then B1)   XHb: rows {64..127}
-// in a ring of FIVE slots, piece h = 3 kt + type in slot h % 5 (pieces are issued in increasing h).
-//
-// Schedule (ONE barrier per phase; a wave finishes its own LDS reads -- lgkmcnt(0) -- before the barrier):
-//     phase (t,0): read XHa_t, W_t[B0]; issue W_{t+1}                      [slot of XHb_{t-1}: last read (t-1,2)]
-//     phase (t,1): read W_t[B1];        wait until XHb_t has landed          (keeps XHa_{t+1}, W_{t+1} in flight: vmcnt(8))
-//     phase (t,2): read XHb_t;          issue XHb_{t+1}                     [slot of XHa_t: last read (t,0)]
-//     phase (t,3): no read;             issue XHa_{t+2}; wait until XHa_{t+1}, W_{t+1} have landed (keeps the two youngest)
-//                                                                            [slot of W_t: last read (t,1)]
-//   RAW: every piece is read at the earliest one phase after the wait (by every wave, followed by the barrier) that
-//        retires it.  WAR: a slot is re-staged at the earliest in the phase after the one whose barrier followed its last
-//        read.  The waits shrink at the end of K as pieces stop being issued.
-template <int EPI>
-__device__ __forceinline__ void pp2_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles) {
-  constexpr int PIECE = 16384;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  int bid = phys_id;
-  {
-    const int nblk = n_tiles;
-    const int q8 = nblk >> 3, r8 = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  int tile_m, tile_n;
-  if (a.m_major) {
-    tile_m = bid / a.tiles_n;
-    tile_n = bid - tile_m * a.tiles_n;
-  } else {
-    tile_n = bid / a.tiles_m;
-    tile_m = bid - tile_n * a.tiles_m;
-  }
-  const int m0 = tile_m * 256, n0 = tile_n * 128;
-
-  // DMA sources: thread tid moves chunks i = tid + 256 j (j < 4) of every piece; LDS row r = i >> 3 holds, at physical
-  // chunk i & 7, the logical chunk (i & 7) ^ ((r >> 1) & 7) of its source row
-  const bf16* src[3][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = tid + 256 * j, r = i >> 3, c = (i & 7) ^ ((r >> 1) & 7);
-    const int xa = m0 + (r >> 6) * 128 + (r & 63);
-    const int wn = n0 + (r >> 6) * 64 + ((r >> 5) & 1) * 32 + (r & 31);
-    src[0][j] = a.A + (size_t)min(xa, a.M - 1) * a.lda + c * 8;       // XHa
-    src[1][j] = a.W + (size_t)min(wn, a.N - 1) * a.ldw + c * 8;       // W
-    src[2][j] = a.A + (size_t)min(xa + 64, a.M - 1) * a.lda + c * 8;  // XHb
-  }
-  const int KT = a.K / 64;
-  int islot = 0;  // slot of the next piece to issue
-  auto issue = [&](int type, int kt) {
-    char* dst = smem + islot * PIECE + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16* sp = type == 0 ? src[0][j] : (type == 1 ? src[1][j] : src[2][j]);
-      glds16(sp + kt * 64, dst + j * 4096);
-    }
-    islot = islot == 4 ? 0 : islot + 1;
-  };
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int sw = (fr >> 1) & 7;
-  const int xoff = (wr * 64 + fr) * 128, woff = (wc * 64 + fr) * 128;
-  bf16x8 xf[2][4], wf0[2][2], wf1[2][2];
-  auto read_x = [&](const char* slot) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        xf[kk][j] = *(const bf16x8*)(slot + xoff + j * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
-  };
-  auto read_w = [&](const char* slot, bf16x8 (&wf)[2][2]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        wf[kk][i] = *(const bf16x8*)(slot + woff + i * 16 * 128 + (((kk * 4 + fq) ^ sw) << 4));
-  };
-  auto mfma_quadrant = [&](auto qa_c, auto qb_c, bf16x8 (&wf)[2][2]) {
-    constexpr int qa = decltype(qa_c)::value, qb = decltype(qb_c)::value;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads done BEFORE the barrier: the slot may be re-staged after it
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[qb * 2 + i][qa * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[qb * 2 + i][qa * 4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto wait_keep = [&](int pieces) {   // all but the `pieces` youngest pieces (4 DMAs each) of this wave have landed
-    if (pieces >= 2) wait_vm<8>();
-    else if (pieces == 1) wait_vm<4>();
-    else wait_vm<0>();
-  };
-
-  // prologue: XHa_0, W_0, XHb_0, XHa_1 (dispatch guarantees KT >= 2); the first two must have landed before phase (0,0)
-  issue(0, 0); issue(1, 0); issue(2, 0); issue(0, 1);
-  wait_vm<8>();
-  __builtin_amdgcn_s_barrier();
-
-  int rs = 0;  // slot of XHa_kt; W_kt and XHb_kt follow
-  for (int kt = 0; kt < KT; ++kt) {
-    const int s1 = rs + 1 >= 5 ? rs - 4 : rs + 1, s2 = rs + 2 >= 5 ? rs - 3 : rs + 2;
-    const char* X = smem + rs * PIECE;
-    const char* Wp = smem + s1 * PIECE;
-    const char* Xb = smem + s2 * PIECE;
-    const bool n1 = kt + 1 < KT, n2 = kt + 2 < KT;
-    // phase 0: (A0, B0)
-    read_x(X);
-    read_w(Wp, wf0);
-    if (n1) issue(1, kt + 1);
-    mfma_quadrant(I0{}, I0{}, wf0);
-    // phase 1: (A0, B1)
-    read_w(Wp + 32 * 128, wf1);
-    wait_keep(n1 ? 2 : 0);
-    mfma_quadrant(I0{}, I1{}, wf1);
-    // phase 2: (A1, B1)
-    read_x(Xb);
-    if (n1) issue(2, kt + 1);
-    mfma_quadrant(I1{}, I1{}, wf1);
-    // phase 3: (A1, B0), operands already in registers
-    if (n2) issue(0, kt + 2);
-    wait_keep((n1 ? 1 : 0) + (n2 ? 1 : 0));
-    mfma_quadrant(I1{}, I0{}, wf0);
-    rs = rs + 3 >= 5 ? rs - 2 : rs + 3;
-  }
-  // every wave is past its last LDS read (phase (KT-1,2), before that phase's barrier): the ring is free for the epilogue
-  pp_epilogue<EPI, 0, 0, 0>(a, smem, acc, wave, lane, wr, wc, m0, n0);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_pp2_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
-  // two workgroups share a CU: the second half of the grid starts half a tile late, so that one's epilogue falls into the
-  // other's K loop from the first tile on (~2200 cycles per K-tile measured; s_sleep 127 = 8128 cycles)
-  if (a.pp_stagger && (int)blockIdx.x >= grid / 2) {
-    const int naps = (int)((long long)(a.K / 64) * 1100 / 8128);
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  for (int p = blockIdx.x; p < n_tiles; p += grid) {
-    pp2_tile<EPI>(a, smem, p, n_tiles);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
-template <int EPI>
-int launch_pp2_t(GemmArgs& a, hipStream_t st) {
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 127) / 128;
-  a.m_major = a.M > a.N;
-  constexpr int lds = 5 * 16384;
-  static F5eDeviceOnce lds_once;
-  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp2_kernel<EPI>), lds);
-  int n_cu = f5e_cu_count() / 8 * 8;
-  if (n_cu == 0) n_cu = 8;
-  const char* se = getenv("F5E_PP_STAGGER");
-  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
-  const int n_tiles = a.tiles_m * a.tiles_n;
-  const int grid = n_tiles < 2 * n_cu ? (n_tiles + 7) / 8 * 8 : 2 * n_cu;
-  hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI>), dim3(grid), dim3(256), lds, st, a);
-  F5E_LAUNCH_CHECK("gemm_bf16_pp2");
-  return F5E_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Third schedule ("pp3"): 4 waves, 256 x 256 tile, ONE wave per SIMD with a 128 x 128 wave tile.
-//
-// Why: the 8-wave kernel's K loop is bound by LDS traffic and, through the power cap, by energy per flop (the
-// shader clock sits at 1.4-2.0 GHz inside the loop).  A 128 x 64 wave tile pulls 0.0234 B of fragments out of LDS per
-// flop; 128 x 128 pulls 0.0156 (-33 %): 128 KiB instead of 192 KiB of ds_read per 64-deep K-tile and CU.  128 x 128 fp32
-// accumulators are 256 registers per lane: with ONE wave per SIMD a wave owns the whole 512-entry file, the accumulators
-// live in the AGPR half (MFMA reads / writes them there) and 256 VGPRs stay for two fragment sets + addresses.  Nothing
-// else shares the SIMD, so the wave hides its own latencies: the ds_reads of K-step s + 1 are issued inside the 64 MFMAs
-// (1024 matrix-pipe cycles) of step s.
-//
-// Geometry.  wave = wr * 2 + wc owns rows [128 wr, +128) x columns [128 wc, +128).  K-step = 32 (one 16x16x32 operand
-// per 16 rows): a stage is 32 KiB = A part (256 rows x 64 B) + W part (256 rows x 64 B), ring of FIVE stages = 160 KiB.
-// LDS row = 4 chunks of 16 B; physical chunk = logical chunk ^ ((row >> 2) & 3), applied on the DMA source side and on
-// the ds_read_b128 (the 16 lanes of a read group then cover all 16 bank quads of a 256-byte bank line).
-//
-// Step s (stage s in slot s % 5, fragment set s & 1):
-//     lgkmcnt(0)                         set s & 1 complete (its reads were issued in step s - 1)
-//     16 MFMAs
-//     wait until stage s + 1 has landed (the two younger stages stay in flight), s_barrier
-//         -> every wave's share of stage s + 1 is visible, and every wave is past the lgkmcnt(0) of step s, i.e. done
-//            reading stage s: its slot is free
-//     issue stage s + 5 into the slot of stage s;  ds_read set (s + 1) & 1 from stage s + 1
-//     48 MFMAs
-// RAW: a stage is read only after the wait + barrier that retired it.  WAR: a slot is re-staged only after the barrier
-// that follows every wave's lgkmcnt(0) on the reads of its previous content.
-template <int EPI>
-__device__ __forceinline__ void pp3_tile(const GemmArgs& a, char* smem, int phys_id, int n_tiles, int iter = 0) {
-  constexpr int STG = 32768, NSLOT = 5;
-  const int tid = threadIdx.x;
-  auto stamp = [&](int k) {   // tools build only (a.trace stays null otherwise): tools/pp_timeline.py
-#ifdef F5E_TOOLS
-    if (tid == 0 && a.trace && iter < 16) {
-      a.trace[((size_t)blockIdx.x * 16 + iter) * 4 + k] = __builtin_amdgcn_s_memrealtime();
-      if (k == 1 || k == 2) a.trace[(size_t)gridDim.x * 64 + ((size_t)blockIdx.x * 16 + iter) * 2 + (k - 1)] = __builtin_readcyclecounter();
-    }
-#endif
-  };
-  stamp(0);
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  int bid = phys_id;
-  {
-    const int nblk = n_tiles;
-    const int q8 = nblk >> 3, r8 = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  int tile_m, tile_n;
-  if (a.m_major) {
-    tile_m = bid / a.tiles_n;
-    tile_n = bid - tile_m * a.tiles_n;
-  } else {
-    tile_n = bid / a.tiles_m;
-    tile_m = bid - tile_n * a.tiles_m;
-  }
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-
-  // DMA sources: thread tid moves chunks ci = tid + 256 j (j < 4) of the A part and of the W part; row = ci >> 2
-  const bf16* asrc[4];
-  const bf16* wsrc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ci = tid + 256 * j, row = ci >> 2, lc = (ci & 3) ^ ((row >> 2) & 3);
-    asrc[j] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + lc * 8;
-    wsrc[j] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + lc * 8;
-  }
-  const int S = a.K / 32;
-  auto issue = [&](int slot, int st) {
-    char* dst = smem + slot * STG + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(asrc[j] + st * 32, dst + j * 4096);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(wsrc[j] + st * 32, dst + 16384 + j * 4096);
-  };
-
-  f32x4 accL[4][8], accH[4][8];  // columns [0, 64) / [64, 128) of the wave tile, the layout pp_epilogue takes
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accL[i][j] = accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fo = (fq ^ ((fr >> 2) & 3)) << 4;
-  const int xoff = (wr * 128 + fr) * 64 + fo, woff = 16384 + (wc * 128 + fr) * 64 + fo;
-  bf16x8 xf0[8], wf0[8], xf1[8], wf1[8];
-  auto read_set = [&](const char* slot, bf16x8 (&xf)[8], bf16x8 (&wf)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(slot + xoff + j * 1024);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) wf[i] = *(const bf16x8*)(slot + woff + i * 1024);
-  };
-  auto mfma_rows = [](auto i0_c, auto n_c, f32x4 (&accL)[4][8], f32x4 (&accH)[4][8], bf16x8 (&xf)[8], bf16x8 (&wf)[8]) {  // column blocks [i0, i0 + n) of the 8
-    constexpr int i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
-#pragma unroll
-    for (int i = i0; i < i0 + n; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // inline asm with an AGPR constraint: left to itself hipcc keeps part of the 256 accumulators in VGPRs and shuffles
-        // them through v_accvgpr_write around every MFMA (4 VALU issues per 16-cycle MFMA).  Hazards the compiler cannot
-        // see inside asm: an accumulator is touched once per 64 MFMAs (no back-to-back dependency), and the loop is
-        // followed by explicit wait states before the epilogue reads the AGPRs.
-        if (i < 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accL[i][j]) : "v"(wf[i]), "v"(xf[j]));
-        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accH[i - 4][j]) : "v"(wf[i]), "v"(xf[j]));
-      }
-  };
-  auto wait_young = [&](int stages) {  // all but the `stages` youngest stages (8 DMAs each) of this wave have landed
-    if (stages >= 3) wait_vm<24>();
-    else if (stages == 2) wait_vm<16>();
-    else if (stages == 1) wait_vm<8>();
-    else wait_vm<0>();
-  };
-  using C0 = std::integral_constant<int, 0>;
-  using C2 = std::integral_constant<int, 2>;
-  using C6 = std::integral_constant<int, 6>;
-
-  // prologue: stages 0 .. 3; stage 0 must have landed before the first reads
-  int n_issued = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (t < S) { issue(t, t); ++n_issued; }
-  wait_young(n_issued - 1);
-  __builtin_amdgcn_s_barrier();
-  stamp(1);
-  read_set(smem, xf0, wf0);
-
-  int slot_next = 1;   // slot of stage s + 1
-  int slot_free = 4;   // slot that stage s + 4 goes into at step s: (s + 4) % 5
-  auto advance = [&]() {
-    slot_next = slot_next == NSLOT - 1 ? 0 : slot_next + 1;
-    slot_free = slot_free == NSLOT - 1 ? 0 : slot_free + 1;
-  };
-  auto mf = [](f32x4 (&accL)[4][8], f32x4 (&accH)[4][8], bf16x8 (&xf)[8], bf16x8 (&wf)[8], int i, int j) {
-    if (i < 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accL[i][j]) : "v"(wf[i]), "v"(xf[j]));
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accH[i - 4][j]) : "v"(wf[i]), "v"(xf[j]));
-  };
-  // Main-loop step (s + 4 < S): with one wave per SIMD nothing else feeds the matrix pipe, so the step's 8 LDS-DMAs and 16
-  // ds_reads are spread BETWEEN its MFMAs (two MFMAs = 32 pipe cycles per memory instruction) instead of issued in a
-  // bunch during which the pipe would drain; sched_barrier pins each of them in its slot.
-  auto step_full = [&](int s, bf16x8 (&xf)[8], bf16x8 (&wf)[8], bf16x8 (&xn)[8], bf16x8 (&wn)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    mfma_rows(C0{}, C2{}, accL, accH, xf, wf);
-    wait_vm<16>();   // stage s + 1 landed; s + 2, s + 3 stay in flight
-    __builtin_amdgcn_s_barrier();
-    char* dst = smem + slot_free * STG + wave * 1024;
-    const char* rd = smem + slot_next * STG;
-    // reads first (the last one is followed by >= 16 MFMAs = 256 pipe cycles before the next step's lgkmcnt(0)), DMAs last
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      if (g < 8) xn[g] = *(const bf16x8*)(rd + xoff + g * 1024);
-      else wn[g - 8] = *(const bf16x8*)(rd + woff + (g - 8) * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      mf(accL, accH, xf, wf, 2 + (g >> 2), (2 * g) & 7);
-      mf(accL, accH, xf, wf, 2 + (g >> 2), (2 * g + 1) & 7);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g < 4) glds16(asrc[g] + (s + 4) * 32, dst + g * 4096);
-      else glds16(wsrc[g - 4] + (s + 4) * 32, dst + 16384 + (g - 4) * 4096);
-      __builtin_amdgcn_sched_barrier(0);
-      mf(accL, accH, xf, wf, 6 + (g >> 2), (2 * g) & 7);
-      mf(accL, accH, xf, wf, 6 + (g >> 2), (2 * g + 1) & 7);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    advance();
-  };
-  auto step = [&](int s, bf16x8 (&xf)[8], bf16x8 (&wf)[8], bf16x8 (&xn)[8], bf16x8 (&wn)[8]) {  // tail steps
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    mfma_rows(C0{}, C2{}, accL, accH, xf, wf);
-    // stages issued so far: min(s + 3, S - 1) is the youngest (step s - 1 issued stage s + 3); stage s + 1 must have landed
-    const int youngest = s + 3 < S - 1 ? s + 3 : S - 1;
-    wait_young(youngest - (s + 1) > 0 ? youngest - (s + 1) : 0);
-    __builtin_amdgcn_s_barrier();
-    if (s + 4 < S) issue(slot_free, s + 4);
-    if (s + 1 < S) read_set(smem + slot_next * STG, xn, wn);
-    mfma_rows(C2{}, C6{}, accL, accH, xf, wf);
-    advance();
-  };
-  int s = 0;
-  for (; s + 5 < S; s += 2) {   // S is even (K % 64 == 0); both steps of the pair still issue a stage
-    step_full(s, xf0, wf0, xf1, wf1);
-    step_full(s + 1, xf1, wf1, xf0, wf0);
-  }
-  for (; s < S; s += 2) {
-    step(s, xf0, wf0, xf1, wf1);
-    step(s + 1, xf1, wf1, xf0, wf0);
-  }
-  // every wave is past the last step's barrier, i.e. past its last LDS read: the ring is free for the epilogue
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA write -> v_accvgpr_read wait states (asm MFMAs: see mfma_rows)
-  stamp(2);
-  pp_epilogue<EPI, 0, 0, 0>(a, smem, accL, wave * 2, lane, wr, wc * 2, m0, n0);
-  pp_epilogue<EPI, 0, 0, 0>(a, smem, accH, wave * 2 + 1, lane, wr, wc * 2 + 1, m0, n0);
-  stamp(3);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_pp3_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n_tiles = a.tiles_m * a.tiles_n, grid = gridDim.x;
-  const int extra = n_tiles % grid;
-  if (a.pp_stagger && extra > 0 && (int)blockIdx.x >= extra) {
-    const long long slack = (long long)(a.K / 64) * 5000;
-    const int naps = (int)(slack * ((int)blockIdx.x - extra) / (grid - extra) / 8128);
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  int iter = 0;
-  for (int p = blockIdx.x; p < n_tiles; p += grid, ++iter) {
-    pp3_tile<EPI>(a, smem, p, n_tiles, iter);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // epilogue LDS reads done before the next prologue's DMAs land
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
-template <int EPI>
-int launch_pp3_t(GemmArgs& a, hipStream_t st) {
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 255) / 256;
-  a.m_major = a.M > a.N;
-  a.rps_magic = div_magic_of(a.rows_per_seq);
-  constexpr int lds = 5 * 32768;
-#ifdef F5E_TOOLS
-  a.trace = getenv("F5E_PP_TRACE") ? (unsigned long long*)strtoull(getenv("F5E_PP_TRACE"), nullptr, 0) : nullptr;
-#endif
-  static F5eDeviceOnce lds_once;
-  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp3_kernel<EPI>), lds);
-  int n_cu = f5e_cu_count() / 8 * 8;
-  if (n_cu == 0) n_cu = 8;
-  const char* se = getenv("F5E_PP_STAGGER");
-  a.pp_stagger = (se && se[0] == '0') ? 0 : 1;
-  const int n_tiles = a.tiles_m * a.tiles_n;
-  const int grid = n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu;
-  hipLaunchKernelGGL((gemm_bf16_pp3_kernel<EPI>), dim3(grid), dim3(256), lds, st, a);
-  F5E_LAUNCH_CHECK("gemm_bf16_pp3");
-  return F5E_OK;
-}
-
-template <int EPI, int DBG = 0, int FUSE = 0>
+template <int EPI, int TRACE = 0>
 int launch_pp_t(GemmArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
   a.m_major = a.M > a.N;
   a.rps_magic = div_magic_of(a.rows_per_seq);
-  constexpr int lds = 8 * HALF_BYTES + (FUSE == 1 ? 4096 : 0);
+  constexpr int lds = 8 * HALF_BYTES;
   static F5eDeviceOnce lds_once;  // 128 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, DBG, FUSE>), lds);
+  F5E_OPT_IN_LDS(lds_once, (gemm_bf16_pp_kernel<EPI, TRACE>), lds);
   int n_cu = f5e_cu_count() / 8 * 8;
   if (n_cu == 0) n_cu = 8;
-  const char* se = getenv("F5E_PP_STAGGER");  // default on (2-4 % at C3); 0 switches it off for A/B runs
-  a.pp_stagger = (se && se[0] == '0') ? 0 : ((se && se[0] == '2') ? 2 : 1);
-  static const int ngroup_env = getenv("F5E_PP_NGROUP") ? atoi(getenv("F5E_PP_NGROUP")) : 4;
-  a.pp_ngroup = (ngroup_env > 0 && a.tiles_n > ngroup_env) ? ngroup_env : 0;
+  // column groups of 4 n-tiles (for QKV exactly the q, k and v blocks): see pp_tile; 2 / 3 / 6 measured no better
+  a.pp_ngroup = a.tiles_n > 4 ? 4 : 0;
   const int n_tiles = a.tiles_m * a.tiles_n;
-#ifdef F5E_TOOLS
-  if (DBG >= 7) a.trace = getenv("F5E_PP_TRACE") ? (unsigned long long*)strtoull(getenv("F5E_PP_TRACE"), nullptr, 0) : nullptr;
-#endif
-  const char* pe = getenv("F5E_PP_PERSIST");  // read every launch: A/B switch for tuning runs
-  const int grid = (pe && pe[0] == '0') ? n_tiles : (n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu);
-  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, DBG, FUSE>), dim3(grid), dim3(512), lds, st, a);
+  // persistent: one workgroup per CU (a multiple of 8, so a workgroup keeps its XCD class across its tiles)
+  const int grid = n_tiles < n_cu ? (n_tiles + 7) / 8 * 8 : n_cu;
+  hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, TRACE>), dim3(grid), dim3(512), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16_pp");
   return F5E_OK;
 }
@@ -1107,62 +573,20 @@ int launch_pp_t(GemmArgs& a, hipStream_t st) {
 
 namespace f5e_gemm {
 
-int launch_pp(int epi, GemmArgs& a, hipStream_t st, int dbg) {
+int launch_pp(int epi, GemmArgs& a, hipStream_t st) {
   F5E_REQUIRE(a.K % 64 == 0 && a.K >= 128, "gemm_bf16_pp: K=%d must be a multiple of 64 and >= 128", a.K);
-  static const int pp2_env = getenv("F5E_PP2") ? atoi(getenv("F5E_PP2")) : 0;
-  if ((dbg == 8 || (dbg == 0 && pp2_env)) && !a.ln_stats && !a.stats_out) {
-    switch (epi) {
-      case EPI_BF16: return launch_pp2_t<EPI_BF16>(a, st);
-      case EPI_BF16_GELU: return launch_pp2_t<EPI_BF16_GELU>(a, st);
-      case EPI_GATE_RES: return launch_pp2_t<EPI_GATE_RES>(a, st);
-      case EPI_QKV_ROPE: return launch_pp2_t<EPI_QKV_ROPE>(a, st);
-      case EPI_F32: return launch_pp2_t<EPI_F32>(a, st);
-    }
-  }
-  static const int pp3_env = getenv("F5E_PP3") ? atoi(getenv("F5E_PP3")) : 0;
-  if ((dbg == 11 || (dbg == 0 && pp3_env)) && !a.ln_stats && !a.stats_out) {   // tile_hint 119
-    switch (epi) {
-      case EPI_BF16: return launch_pp3_t<EPI_BF16>(a, st);
-      case EPI_BF16_GELU: return launch_pp3_t<EPI_BF16_GELU>(a, st);
-      case EPI_GATE_RES: return launch_pp3_t<EPI_GATE_RES>(a, st);
-      case EPI_QKV_ROPE: return launch_pp3_t<EPI_QKV_ROPE>(a, st);
-      case EPI_F32: return launch_pp3_t<EPI_F32>(a, st);
-    }
-  }
-  if (dbg == 8 || dbg == 11) dbg = 0;
-  if (dbg == 1) return launch_pp_t<EPI_BF16_GELU, 1>(a, st);
-  if (dbg == 2) return launch_pp_t<EPI_BF16_GELU, 2>(a, st);
-  if (dbg == 3) return launch_pp_t<EPI_BF16_GELU, 3>(a, st);
-  if (dbg == 4) return launch_pp_t<EPI_BF16_GELU, 4>(a, st);
-  if (dbg == 5) return launch_pp_t<EPI_BF16_GELU, 5>(a, st);
-  if (dbg == 6) return launch_pp_t<EPI_BF16_GELU, 6>(a, st);
+  F5E_REQUIRE(!a.ln_stats && !a.stats_out, "gemm_bf16_pp: the fused AdaLN runs on the 64x64 tile family");
 #ifdef F5E_TOOLS
-  if (dbg == 9) return launch_pp_t<EPI_BF16_GELU, 9>(a, st);
-  if (dbg == 10) return launch_pp_t<EPI_BF16_GELU, 10>(a, st);
-  if (dbg == 7) {
+  // tools build only (tools/pp_timeline.py): per-tile timestamps into the buffer named by F5E_PP_TRACE
+  if (const char* tr = getenv("F5E_PP_TRACE")) {
+    a.trace = (unsigned long long*)strtoull(tr, nullptr, 0);
     switch (epi) {
-      case EPI_GATE_RES: return launch_pp_t<EPI_GATE_RES, 7>(a, st);
-      case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 7>(a, st);
-      default: return launch_pp_t<EPI_BF16_GELU, 7>(a, st);
+      case EPI_GATE_RES: return launch_pp_t<EPI_GATE_RES, 1>(a, st);
+      case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 1>(a, st);
+      default: return launch_pp_t<EPI_BF16_GELU, 1>(a, st);
     }
   }
 #endif
-  if (a.ln_stats) {   // fused-AdaLN consumer (checked by the dispatcher: one table row)
-    F5E_REQUIRE(a.ln_rowstats, "gemm_bf16_pp: the large-M AdaLN consumer needs f5e_ln_fuse.row_stats (f5e_ln_finalize)");
-    switch (epi) {
-      case EPI_BF16: return launch_pp_t<EPI_BF16, 0, 1>(a, st);
-      case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU, 0, 1>(a, st);
-      case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 0, 1>(a, st);
-      case EPI_F32: return launch_pp_t<EPI_F32, 0, 1>(a, st);
-    }
-    f5e_set_error("gemm_bf16_pp: epilogue %d cannot consume AdaLN statistics", epi);
-    return F5E_ERR_BAD_SHAPE;
-  }
-  if (a.stats_out) {  // producer: gate + residual only, full 64-column strips, one gate row
-    F5E_REQUIRE(epi == EPI_GATE_RES && a.N % 64 == 0 && a.gate_rows == 1 && a.N % 4 == 0,
-                "gemm_bf16_pp: the AdaLN producer is the gate+residual epilogue with N %% 64 == 0 and one gate row");
-    return launch_pp_t<EPI_GATE_RES, 0, 2>(a, st);
-  }
   switch (epi) {
     case EPI_BF16: return launch_pp_t<EPI_BF16>(a, st);
     case EPI_BF16_GELU: return launch_pp_t<EPI_BF16_GELU>(a, st);

@@ -100,24 +100,6 @@ __global__ __launch_bounds__(256) void layernorm_any_kernel(LnArgs a) {
   }
 }
 
-// Large-M fused AdaLN: (mean, M2) tile partials [rows][parts][2] -> (mean, rstd) [rows][2], one thread per row (a row's
-// partials are one or two full cache lines).  Chan's formula in the fixed order the small-M consumer uses.
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* stats, int parts, float inv_d, float cols, float eps,
-                                                           int rows, float* row_stats) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows) return;
-  const f32x2* sp = (const f32x2*)(stats + (size_t)r * parts * 2);
-  float sm = 0.f;
-  for (int p = 0; p < parts; ++p) sm += sp[p][0];
-  const float mean = sm / (float)parts;
-  float m2 = 0.f;
-  for (int p = 0; p < parts; ++p) {
-    const float dm = sp[p][0] - mean;
-    m2 += sp[p][1] + cols * dm * dm;
-  }
-  *(f32x2*)(row_stats + (size_t)r * 2) = f32x2{mean, rsqrtf(m2 * inv_d + eps)};
-}
-
 // Head of the fused-AdaLN chain (see f5e_ln_fuse in the ABI header): no normalisation here, only the row statistics and
 // the pre-scaled bf16 copy the first consumer GEMM runs on.
 template <int VPL>
@@ -302,14 +284,6 @@ int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int
     default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, a); break;
   }
   F5E_LAUNCH_CHECK("layernorm");
-  return F5E_OK;
-}
-
-int f5e_ln_finalize(hipStream_t st, const float* stats, int parts, int D, float eps, int rows, float* row_stats) {
-  F5E_REQUIRE(stats && row_stats && rows > 0 && parts > 0 && D > 0 && D % parts == 0, "ln_finalize: bad arguments");
-  hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, stats, parts, 1.0f / (float)D,
-                     (float)(D / parts), eps, rows, row_stats);
-  F5E_LAUNCH_CHECK("ln_finalize");
   return F5E_OK;
 }
 

@@ -2,7 +2,6 @@
 // that chains the per-op kernels for one network call (reference backbones/dit.py:452-470, model/modules.py:627-641).
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
@@ -96,7 +95,6 @@ int f5e_workspace_bytes(const f5e_dit_plan* p, f5e_dit_workspace* out) {
   b[F5E_WS_LN_STATS] = p->fuse_ln ? M * (D / 64) * 2 * 4 : 0;
   b[F5E_WS_SKIP_RES] = p->w_skip ? M * D * 4 : 0;
   b[F5E_WS_SKIP_TMP] = p->w_skip ? M * D * 4 : 0;
-  b[F5E_WS_LN_ROWSTATS] = p->fuse_ln ? (M + 1) * 2 * 4 : 0;
   unsigned long long off = 0;
   for (int i = 0; i < F5E_WS_COUNT; ++i) {
     out->offset[i] = off;
@@ -224,21 +222,11 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     // Infinity-Cache prefetch (f5e_common.h): every GEMM / attention launch of a block drags the weights of the launch after
     // next into the memory-side cache with a few grid-tail workgroups, so the batch-1 GEMMs stop waiting for HBM.
     const bool pfon = p->mall_prefetch != 0;
-    // Who hosts what (F5E_PF_SCHEME, A/B switch; measured at C2, ms per pass: off 48.35, 0: 47.45, 1: 46.41):
-    //   0: QKV -> w_out, attention -> w_ff1, OUT -> w_ff2, FF1 -> next w_qkv
-    //   1: the same with FF2 (one workgroup per CU: room for the extra ones) hosting next w_qkv instead of FF1 (two per CU)
-    //   2: attention (hosts for free: it is not bound by the memory pipe) -> w_ff1 + w_ff2, OUT -> next w_qkv, FF1 / FF2 none
-    static const int pf_scheme = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : 1;
+    // Who hosts what: QKV -> w_out, attention (not bound by the memory pipe: hosts for free) -> w_ff1, OUT -> w_ff2, FF2 (one
+    // workgroup per CU: room for the extra ones) -> the next block's w_qkv.  Measured at C2, ms per pass: off 48.35; FF1
+    // hosting the next w_qkv instead of FF2 47.45; this scheme 46.41; attention hosting both FF weights 46.95.
     const unsigned b_out = (unsigned)((size_t)D * inner * 2), b_ff = (unsigned)((size_t)p->FF * D * 2);
     const unsigned b_qkv = (unsigned)((size_t)3 * inner * D * 2);
-    // Large M (the 256x256 kernel): a workgroup of a consumer GEMM reads finalized (mean, rstd) rows, made once per producer
-    // by f5e_ln_finalize, instead of combining 8 * parts bytes per row in each of its up to 12 column tiles.
-    const bool big = f5e_gemm::uses_pp(M, D);
-    if (big) {
-      F5E_REQUIRE(p->ln_rowstats, "dit_forward: fused AdaLN at this many rows needs the ln_rowstats workspace");
-      cons.row_stats = p->ln_rowstats;
-      F5E_TRY(f5e_ln_finalize(st, p->ln_stats, parts, D, 1e-6f, M, p->ln_rowstats));
-    }
     for (int l = 0; l < p->L; ++l) {
       const f5e_dit_block_weights& w = p->blocks[l];
       F5E_REQUIRE(!w.q_norm_w, "dit_forward: fused AdaLN and qk_norm are exclusive");
@@ -247,9 +235,8 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
       const F5ePrefetch pf_next{{l + 1 < p->L ? p->blocks[l + 1].w_qkv : p->w_proj, nullptr},
                                 {l + 1 < p->L ? b_qkv : (unsigned)((size_t)p->mel * D * 2), 0}};
       const F5ePrefetch pf_qkv{{w.w_out, nullptr}, {b_out, 0}};
-      const F5ePrefetch pf_attn = pf_scheme == 2 ? F5ePrefetch{{w.w_ff1, w.w_ff2}, {b_ff, b_ff}} : F5ePrefetch{{w.w_ff1, nullptr}, {b_ff, 0}};
-      const F5ePrefetch pf_out = pf_scheme == 2 ? pf_next : F5ePrefetch{{w.w_ff2, nullptr}, {b_ff, 0}};
-      const F5ePrefetch& pf_ff1 = pf_next;
+      const F5ePrefetch pf_attn{{w.w_ff1, nullptr}, {b_ff, 0}};
+      const F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
       cons.c = cdl; cons.d = cdl + 3 * inner;
       F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_pf(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
                                         p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons, pfon ? &pf_qkv : nullptr));
@@ -259,16 +246,14 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
       F5E_TIMED(F5E_OP_OUT, f5e_gemm_bf16_gate_residual_pf(st, p->ao, inner, w.w_out, inner, w.b_out, p->x, D, mb + 2 * D,
                                           row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, p->seq_len, M, D,
                                           inner, 0, &prod, pfon ? &pf_out : nullptr));
-      if (big) F5E_TRY(f5e_ln_finalize(st, p->ln_stats, parts, D, 1e-6f, M, p->ln_rowstats));
       cons.c = cdl + 6 * inner; cons.d = cdl + 6 * inner + p->FF;
       F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_pf(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
-                                    F5E_ACT_GELU_TANH, 0, 0, &cons, (pfon && pf_scheme == 0) ? &pf_ff1 : nullptr));
+                                    F5E_ACT_GELU_TANH, 0, 0, &cons, nullptr));
       // next norm: attn_norm of block l+1 (scale_msa at +D) or the final AdaLN (scale first: modules.py:333)
       prod.next_scale = (l + 1 < p->L) ? mb + 6 * D + D : p->mod + (size_t)p->L * 6 * D;
       F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_pf(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,
                                           row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF,
-                                          0, &prod, (pfon && pf_scheme == 1) ? &pf_ff1 : nullptr));
-      if (big) F5E_TRY(f5e_ln_finalize(st, p->ln_stats, parts, D, 1e-6f, M, p->ln_rowstats));
+                                          0, &prod, pfon ? &pf_next : nullptr));
     }
     cons.c = p->cd + (size_t)p->L * ls; cons.d = cons.c + p->mel;
     F5E_TIMED(F5E_OP_FINAL, f5e_gemm_bf16_bias_ln(st, p->hn, D, p->w_proj, D, nullptr, p->pred, p->mel, M, p->mel, D,

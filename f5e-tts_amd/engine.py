@@ -155,11 +155,6 @@ class DiTEngine:
                          else 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(dv).contiguous()
         # fold the AdaLN LayerNorms into the GEMMs in run_ode when the architecture allows it (F5E_FUSE_LN=0: A/B switch)
         self.fuse_ln = os.environ.get("F5E_FUSE_LN", "1") != "0"
-        # The large-M (ping-pong GEMM) form of the same is built and tested but OFF by default: at C3 it trades the two
-        # LayerNorm launches of a block (2 x 60 us at the HBM roofline) for +82 us of GEMM epilogue (xs stores, in-place
-        # normalise, register pressure at 256 VGPRs) and three 5 us finalize launches -- break-even within run-to-run noise
-        # (24.8 k vs 24.9 k mel-frames/s, profiles/r02_f_*).  F5E_FUSE_LN_PP=1 switches it on.
-        self.fuse_ln_pp = os.environ.get("F5E_FUSE_LN_PP", "0") != "0"
         self.mall_prefetch = os.environ.get("F5E_MALL_PREFETCH", "1") != "0"  # Infinity-Cache weight prefetch at small M
         self._loops = threading.local()   # per-thread LRU of persistent loop states (see _LoopState)
         self._tables: Dict[tuple, Tensor] = {}
@@ -196,13 +191,12 @@ class DiTEngine:
 
     # Above this many rows per launch the 128x128 GEMM tiles win (QKV / FF1 at M = 3752: 41 / 23 us against 54 / 31 us for
     # the 64x64 tile the fusion needs, i.e. more than the two LayerNorm launches it saves): keep LayerNorm separate there.
-    # From 44 row tiles of 256 on (gemm_bf16.hip's crossover) the GEMMs run the 256x256 ping-pong kernel, which can carry the
-    # fusion too (opt-in, see fuse_ln_pp): at C3 each LayerNorm launch is 369 MB of HBM traffic, the fused form 123 MB.
+    # (A large-M form of the fusion on the 256x256 kernel was built and measured twice in round 2: break-even at C3 -- the
+    # fused form moves as many bytes as the roofline-bound LayerNorm it replaces, in less favourable patterns)
     LN_FUSE_MAX_ROWS = 2800
-    LN_FUSE_PP_MIN_ROWS = 43 * 256 + 1
 
     def fuse_rows_ok(self, M: int) -> bool:
-        return M <= self.LN_FUSE_MAX_ROWS or (M >= self.LN_FUSE_PP_MIN_ROWS and self.fuse_ln_pp)
+        return M <= self.LN_FUSE_MAX_ROWS
 
     @property
     def can_fuse_ln(self) -> bool:
@@ -296,6 +290,14 @@ class DiTEngine:
         if text is None:
             ids = torch.zeros(B, N, dtype=I32, device=dv)
         else:
+            if text.device.type == "cpu" and text[:, :N].numel():
+                # nn.Embedding raises IndexError on an id outside the table (reference backbones/dit.py:59,68: after the
+                # truncation to N and the +1 shift): a vocabulary / checkpoint mismatch must not turn into wrong audio.
+                # Host-side ids: no sync.
+                hi, lo = int(text[:, :N].max()), int(text[:, :N].min())
+                if hi + 1 >= self.text_table.shape[0] or lo < -1:
+                    raise IndexError(f"index out of range in self: token id {hi if hi + 1 >= self.text_table.shape[0] else lo} "
+                                     f"with text_num_embeds = {self.text_table.shape[0] - 1}")
             ids = (h2d(text, dv) + 1)[:, :N]
             ids = torch.nn.functional.pad(ids, (0, N - ids.shape[1]), value=0)
             if cfg.text_mask_padding:
@@ -484,6 +486,7 @@ class _LoopState:
 
     def __init__(self):
         self.uses = 0
+        self.nbytes = 0
         self.step_graph: Optional[ops.Graph] = None
         self.loop_graph: Optional[ops.Graph] = None
         self.buf: dict = {}
@@ -497,6 +500,7 @@ class _LoopState:
 
 
 LOOP_CACHE_ENTRIES = 8   # per thread; a C4-style stream of distinct lengths just cycles through them
+LOOP_CACHE_BYTES = 24 << 30   # ... and at most this much device memory per thread (a C3-size state pins ~1.7 GB of arena)
 
 
 @dataclass
@@ -597,20 +601,46 @@ def ode_setup(engine: DiTEngine, inp: SamplerInputs) -> dict:
 
 
 def _loop_state(engine: DiTEngine, key: tuple, persistent: bool) -> Tuple[_LoopState, bool]:
-    """The calling thread's state for `key` (LRU), or a throw-away one for eager / instrumented runs."""
+    """The calling thread's state for `key` (LRU), or a throw-away one for eager / instrumented runs.  A fresh state is NOT
+    yet in the cache: run_ode publishes it (_publish_state) once its buffers, plans and first capture exist, so a failed
+    allocation never leaves a half-built entry behind."""
     if not persistent:
         return _LoopState(), True
     cache = getattr(engine._loops, "cache", None)
     if cache is None:
         cache = engine._loops.cache = {}
     st = cache.pop(key, None)
-    fresh = st is None
-    if fresh:
-        st = _LoopState()
-        while len(cache) >= LOOP_CACHE_ENTRIES:
-            cache.pop(next(iter(cache))).retire()      # parked behind an event, destroyed once its launches ran
-    cache[key] = st                                     # most recently used last
-    return st, fresh
+    if st is not None:
+        cache[key] = st                                 # most recently used last
+        return st, False
+    return _LoopState(), True
+
+
+def _publish_state(engine: DiTEngine, key: tuple, st: _LoopState) -> None:
+    """Insert a fully built state and evict least-recently-used ones beyond LOOP_CACHE_ENTRIES entries or
+    LOOP_CACHE_BYTES of device memory.  This runs on the CAPTURE stream, so evicted graphs are only queued here
+    (engine._loops.pending); CFM._integrate parks them behind an event on the CALLER's stream (retire_pending) -- an event
+    recorded on a stream that later captures would be polled by other threads' Graph.reap() during that capture, which
+    invalidates it."""
+    st.nbytes = sum(t.numel() * t.element_size() for t in st.buf.values() if isinstance(t, Tensor))
+    for pl in (st.plans_a or []) + (st.plans_b or []):
+        st.nbytes += pl.ws["arena"].numel()
+    cache = engine._loops.cache
+    cache[key] = st
+    pending = getattr(engine._loops, "pending", None)
+    if pending is None:
+        pending = engine._loops.pending = []
+    while len(cache) > 1 and (len(cache) > LOOP_CACHE_ENTRIES or sum(x.nbytes for x in cache.values()) > LOOP_CACHE_BYTES):
+        pending.append(cache.pop(next(iter(cache))))
+
+
+def retire_pending(engine: DiTEngine) -> None:
+    """Park the graphs of evicted loop states behind an event on the CURRENT stream and free the finished ones.  Call it on
+    the caller's stream after it has been ordered behind the capture stream (CFM._integrate), never while capturing."""
+    pending = getattr(engine._loops, "pending", None)
+    while pending:
+        pending.pop().retire()
+    ops.Graph.reap()
 
 
 def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
@@ -742,7 +772,6 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         return gr
 
     if persistent:
-        ops.Graph.reap()
         st.uses += 1
         if st.loop_graph is None and st.uses >= 2 and LOOP_GRAPH:
             st.loop_graph = capture(steps)         # this shape came back: from now on one launch per call
@@ -751,6 +780,8 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         else:
             if st.step_graph is None:
                 st.step_graph = capture(1)
+            if fresh:
+                _publish_state(engine, key, st)    # buffers, plans and the first capture exist: now it may be reused
             for i in range(steps):
                 st.step_graph.launch()
     else:

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _C
-from ..engine import SamplerInputs, h2d, ode_setup, run_ode
+from ..engine import SamplerInputs, h2d, ode_setup, retire_pending, run_ode
 from .modules import MelSpec
 from .utils import default, exists, intersperse, lens_to_mask, list_str_to_idx, list_str_to_tensor
 
@@ -153,6 +153,9 @@ class CFM(nn.Module):
             with torch.cuda.stream(side):
                 trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup)
             cur.wait_stream(side)
+            # graphs of loop states evicted by this call: parked behind an event on the CALLER's stream (which now covers
+            # every launch of the side stream), never on the stream that captures (engine._publish_state)
+            retire_pending(eng)
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)
         self.transformer.clear_cache()

@@ -45,19 +45,9 @@ def _p(t: Optional[Tensor], dtype=None, name="tensor"):
 BF, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 
 
-def ln_finalize(stats: Tensor, D: int, row_stats: Tensor, eps: float = 1e-6):
-    """stats f32 [M, parts, 2] -> row_stats f32 [M + 1, 2] = (mean, rstd) per row (the large-M consumer's input)."""
-    require_device()
-    M, parts, _ = stats.shape
-    check(lib().f5e_ln_finalize(_stream(), _p(stats, F32, "stats"), parts, D, eps, M, _p(row_stats, F32, "row_stats")),
-          "f5e_ln_finalize")
-    return row_stats
-
-
 def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, eval_ptr: Optional[Tensor] = None,
-                cd_eval_stride: int = 0, eps: float = 1e-6, row_stats: Optional[Tensor] = None) -> "_C.LnFuse":
-    """Consumer side of the fused AdaLN (see f5e_ln_fuse): stats f32 [M, parts, 2]; c, d f32 [cd_rows, N] views;
-    row_stats f32 [M + 1, 2] from ln_finalize for launches that take the 256x256 kernel (large M)."""
+                cd_eval_stride: int = 0, eps: float = 1e-6) -> "_C.LnFuse":
+    """Consumer side of the fused AdaLN (see f5e_ln_fuse): stats f32 [M, parts, 2]; c, d f32 [cd_rows, N] views."""
     if c.stride(0) != d.stride(0) or c.shape != d.shape:
         raise _C.F5EError("c and d tables must share shape and row stride")
     f = _C.LnFuse()
@@ -65,8 +55,7 @@ def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, eval_ptr
     f.c, f.d, f.cd_stride, f.cd_rows = c.data_ptr(), d.data_ptr(), c.stride(0), c.shape[0]
     f.cd_eval_stride, f.rows_per_seq, f.eps = cd_eval_stride, rows_per_seq, eps
     f.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
-    f.row_stats = _p(row_stats, F32, "row_stats").value if row_stats is not None else None
-    f._keep = (stats, c, d, eval_ptr, row_stats)
+    f._keep = (stats, c, d, eval_ptr)
     return f
 
 

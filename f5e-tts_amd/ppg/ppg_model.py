@@ -283,14 +283,17 @@ class ConformerEngine:
         ops.gemm_f32(h, self.out_w, self.out_b, out=xs)
         ops.axpby(xs, None, xs, self.xscale, 0.0, 0.0)                         # RelPositionalEncoding: x * sqrt(d)
         pos = self.pos_table(T2)
-        kv_len = len2.to(dv) if B > 1 else None
+        # masks whenever ANY item is shorter than the padded length (reference BaseEncoder always builds them from xs_lens,
+        # ppg/wenet/transformer/encoder.py: also for a single padded utterance); all-full batches need none
+        ragged = bool(int(len2.min()) < T2)
+        kv_len = len2.to(dv) if ragged else None
         keep = None
-        if B > 1:
+        if ragged:
             keep = (torch.arange(T2)[None, :] < len2[:, None].long()).to(F32).to(dv).contiguous()      # mask_pad
         keep_flat = keep.view(-1) if keep is not None else None
         Tp = (T2 + 3) // 4 * 4
         hn = torch.empty(M, D, device=dv)
-        hm = torch.empty(M, D, device=dv) if B > 1 else None
+        hm = torch.empty(M, D, device=dv) if ragged else None
         units = self.layers[0]["ffm"][0].shape[0] if self.layers else D
         mid = torch.empty(M, units, device=dv)
         qu = torch.empty(M, 2 * D, device=dv)

@@ -20,7 +20,14 @@
 extern "C" {
 #endif
 
-#define F5E_ABI_VERSION 1
+#define F5E_ABI_VERSION 2   /* 2: f5e_ln_fuse.row_stats / f5e_ln_finalize / F5E_WS_LN_ROWSTATS removed, f5e_sample_loop added */
+
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#if defined(__GNUC__)
+#define F5E_API __attribute__((visibility("default")))
+#else
+#define F5E_API
+#endif
 
 enum { F5E_OK = 0, F5E_ERR_BAD_SHAPE = -1, F5E_ERR_UNSUPPORTED = -2, F5E_ERR_HIP = -3 };
 
@@ -33,17 +40,18 @@ typedef F5E_STREAM_T f5e_stream; /* library build: the real hipStream_t (same AB
 typedef void* f5e_stream; /* hipStream_t */
 #endif
 
-int f5e_abi_version(void);
-const char* f5e_last_error(void);
+F5E_API int f5e_abi_version(void);
+F5E_API const char* f5e_last_error(void);
 /* 0 when the current HIP device is gfx950; F5E_ERR_UNSUPPORTED otherwise (host call, no kernel launch). */
-int f5e_check_device(void);
+F5E_API int f5e_check_device(void);
 
 /* ---------------------------------------------------------------- bf16 MFMA GEMMs (hot loop) ----------------- */
 
 /* out[M][N] = act(A[M][K] . W[N][K]^T + bias).  A, W bf16; bias f32[N] or NULL; out bf16 (out_f32 = 0) or f32.
- * act: F5E_ACT_NONE or F5E_ACT_GELU_TANH.  K % 64 == 0, N % 4 == 0.  tile_hint 0 = auto.
+ * act: F5E_ACT_NONE or F5E_ACT_GELU_TANH.  K % 64 == 0, N % 4 == 0.  tile_hint: 0 = auto, or force a tile family: 1 = 128x128,
+ * 2 = 128x64, 3 = 64x64, 9 = the 256x256 ping-pong kernel (what auto picks from 44 row tiles of 256 on).
  * Replaces: FeedForward project_in + GELU(tanh) (model/modules.py:348-349,625), proj_out (backbones/dit.py:470). */
-int f5e_gemm_bf16_bias(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+F5E_API int f5e_gemm_bf16_bias(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                        int ldo, int M, int N, int K, int act, int out_f32, int tile_hint);
 
 /* resid[m][n] += gate[(m / rows_per_seq) % gate_rows][n] * (A . W^T + bias)[m][n], skipped for rows whose position
@@ -51,7 +59,7 @@ int f5e_gemm_bf16_bias(f5e_stream st, const void* A, int lda, const void* W, int
  * gate + (*eval_ptr) * eval_stride when eval_ptr != NULL.
  * Replaces: attn.to_out + masked_fill + "x + gate_msa * attn" (modules.py:494-501,635) and
  *           ff.ff[2] + "x + gate_mlp * ff" (modules.py:350,639). */
-int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+F5E_API int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
                                 float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
                                 const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
                                 int N, int K, int tile_hint);
@@ -62,7 +70,7 @@ int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, const voi
  * caller zero-fills them once.
  * q_norm_w / k_norm_w: optional f32[64] RMSNorm weights applied per head before RoPE (qk_norm = "rms_norm", eps 1e-6).
  * Replaces: modules.py:452-461 (projections + head split), :464-467 (qk norm) and :470-480 (apply_rotary_pos_emb). */
-int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
+F5E_API int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
                            void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
                            const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
                            int tile_hint);
@@ -75,7 +83,8 @@ int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W,
  *     tables c[n] = sum_k W[n][k] (1 + scale[k]),  d[n] = sum_k W[n][k] shift[k] + bias[n]  (row r =
  *     (m / rows_per_seq) % cd_rows, advanced by (*eval_ptr) * cd_eval_stride), mean / rstd combined from the
  *     `parts` tile statistics (Chan's formula, fixed order); pass bias = NULL to the GEMM.
- * Only one side is used per launch; leave the other side's pointers NULL.  64x64 tiles (the small-M tile).
+ * Only one side is used per launch; leave the other side's pointers NULL.  Runs on the 64x64 tile family whatever M (the
+ * fusion pays at small row counts, where the LayerNorm launches are pure latency; at large M keep f5e_layernorm).
  * Consumer limits: parts a multiple of 4 up to 16 (D <= 1024), cd_rows == 1 (one table row per evaluation). */
 typedef struct f5e_ln_fuse {
   const float* stats; int parts;                       /* consumer */
@@ -83,22 +92,15 @@ typedef struct f5e_ln_fuse {
   const int* eval_ptr; int rows_per_seq; float eps;
   void* xs_out; int ld_xs; const float* next_scale;    /* producer (next_scale uses the gate's strides / rows) */
   float* stats_out;
-  const float* row_stats;                              /* consumer at LARGE M (the 256x256 kernel): [M + 1][2] = (mean, rstd)
-                                                          per row, made from `stats` by f5e_ln_finalize; NULL at small M */
 } f5e_ln_fuse;
 
-/* Large-M form of the consumer side: combines the `parts` tile statistics of every row once (Chan's formula, fixed order)
- * into row_stats [rows + 1][2] = (mean, rsqrt(var + eps)) (one pad row: the 256x256 kernel fetches them in 16-byte pieces),
- * so that the consumer GEMM's workgroups -- up to 12 per row block -- read 8 bytes per row instead of 8 * parts. */
-int f5e_ln_finalize(f5e_stream st, const float* stats, int parts, int D, float eps, int rows, float* row_stats);
-
-int f5e_gemm_bf16_bias_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+F5E_API int f5e_gemm_bf16_bias_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                           int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln);
-int f5e_gemm_bf16_gate_residual_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+F5E_API int f5e_gemm_bf16_gate_residual_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
                                    float* resid, int ldr, const float* gate, int gate_stride, int gate_rows,
                                    const int* eval_ptr, int eval_stride, int rows_per_seq, const int* seq_len, int M,
                                    int N, int K, int tile_hint, const f5e_ln_fuse* ln);
-int f5e_gemm_bf16_qkv_rope_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
+F5E_API int f5e_gemm_bf16_qkv_rope_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias,
                               void* q, void* k, void* vt, int n_pad, int heads, int rope_heads, const float* cos_sin,
                               const float* q_norm_w, const float* k_norm_w, int rows_per_seq, int M, int K,
                               int tile_hint, const f5e_ln_fuse* ln);
@@ -109,7 +111,7 @@ int f5e_gemm_bf16_qkv_rope_ln(f5e_stream st, const void* A, int lda, const void*
  * q, k, v use the fragment-major layouts documented in csrc/attention.hip; splits: KV splits per 32-query tile
  * (0 = auto, 1, 2 or 4; -1 = the LDS-shared 128-query kernel that auto picks for large problems).
  * Replaces: F.scaled_dot_product_attention + transpose/reshape (modules.py:482-492). */
-int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, void* o, int ldo, const int* kv_len,
+F5E_API int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, void* o, int ldo, const int* kv_len,
                    int S, int H, int rows_per_seq, int n_pad, int splits);
 
 /* ---------------------------------------------------------------- normalisation ------------------------------ */
@@ -118,21 +120,21 @@ int f5e_flash_attn(f5e_stream st, const void* q, const void* k, const void* vt, 
  * x f32 [rows][D]; y bf16 or f32.  D % 256 == 0, D <= 2048.  scale/shift advance by (*eval_ptr) * eval_stride.
  * Replaces: AdaLayerNorm / ff_norm modulation / AdaLayerNorm_Final (modules.py:308-314,329-335,637) and the affine
  * LayerNorms of ConvNeXtV2Block (modules.py:253,264) and Vocos. */
-int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* gamma,
+F5E_API int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* gamma,
                   const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
                   int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps);
 
 /* First producer of the fused-AdaLN chain (block 0 has no GEMM in front of its norm): xs = bf16(x (1 + scale[r]))
  * and stats [rows][parts][2] holding `parts` equal shares (mean, M2 / parts) of each row's statistics. */
-int f5e_adaln_pre(f5e_stream st, const float* x, int ldx, void* xs, int ld_xs, const float* scale, int mod_stride,
+F5E_API int f5e_adaln_pre(f5e_stream st, const float* x, int ldx, void* xs, int ld_xs, const float* scale, int mod_stride,
                   int mod_rows, int rows_per_seq, const int* eval_ptr, int eval_stride, float* stats, int parts,
                   int rows, int D);
 
 /* x_transformers.RMSNorm used by UNetT (backbones/unett.py:151,161,178): y = x / max(||x||_2, 1e-12) * sqrt(D) * g. */
-int f5e_l2norm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D);
+F5E_API int f5e_l2norm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D);
 
 /* GRN over the sequence axis (modules.py:225-234): x, y f32 [B][T][C]; gx_ws f32 [B][C] scratch. */
-int f5e_grn(f5e_stream st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B, int T,
+F5E_API int f5e_grn(f5e_stream st, const float* x, float* y, float* gx_ws, const float* gamma, const float* beta, int B, int T,
             int C);
 
 /* ---------------------------------------------------------------- exact-fp32 GEMM (once per call) ------------ */
@@ -141,7 +143,7 @@ int f5e_grn(f5e_stream st, const float* x, float* y, float* gx_ws, const float* 
  * written to out (f32) and/or out_bf16.  K, lda, ldw multiples of 4.  NULL skips a term.
  * Replaces the fp32 F.linear calls of TimestepEmbedding, AdaLN emb, TextEmbedding, PPGEmbedding, InputEmbedding.proj
  * (x columns per step; cond/text/ppg columns once per call) and Vocos. */
-int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int a_act, const float* W, int ldw,
+F5E_API int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int a_act, const float* W, int ldw,
                  const float* bias, int act, const float* ch_scale, const float* addend, int ld_add, int add_rows,
                  const float* row_scale, float* out, int ldo, void* out_bf16, int ldo_bf16, int M, int N, int K);
 
@@ -150,7 +152,7 @@ int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int a_act, 
 /* One grouped Conv1d(D, D, 31, groups, padding = 15) + Mish of ConvPositionEmbedding (modules.py:167-190, called with
  * mask=None at backbones/dit.py:176).  x bf16 [S*N][ldx]; w_packed bf16 [groups][31][64 oc][64 ic], zero padded when
  * D/groups (16, 32, 48 or 64) is below 64.  mode 0: out_bf16 = mish(conv + bias); mode 1: out_f32 = mish(..) + resid. */
-int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
+F5E_API int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
                 void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
                 int groups);
 
@@ -158,69 +160,69 @@ int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, con
  * (f5e_adaln_pre on its output: xs = bf16(out (1 + scale)), statistics per row and 64-column tile).  One launch when the
  * grid fits the chip in one round, D / groups == 64, parts == groups and mod_rows == 1; otherwise f5e_convpos followed
  * by f5e_adaln_pre -- same results up to fp32 summation order.  Arguments as in those two functions. */
-int f5e_convpos_ln(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, float* out_f32,
+F5E_API int f5e_convpos_ln(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, float* out_f32,
                    int ldo32, const float* resid, int ldr, int S, int N, int D, int groups, void* xs, int ld_xs,
                    const float* scale, int mod_stride, int mod_rows, const int* eval_ptr, int eval_stride, float* stats,
                    int parts);
 
 /* Depthwise Conv1d(C, C, 7, padding 3, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [7][C]. */
-int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
+F5E_API int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
 
 /* col[b][t][j*Cin + ic] = x[b][t + j - pad][ic] (0 outside [0, T)). */
-int f5e_im2col(f5e_stream st, const float* x, float* col, int B, int T, int Cin, int ksize, int pad);
+F5E_API int f5e_im2col(f5e_stream st, const float* x, float* col, int B, int T, int Cin, int ksize, int pad);
 
 /* ---------------------------------------------------------------- sampler elementwise ------------------------ */
 
 /* out[e] = cat(sin(a), cos(a)), a = (scale * t[e]) * freqs[k]   (modules.py:154-161; freqs = host constant [dim/2]) */
-int f5e_sinus_embed(f5e_stream st, const float* t, const float* freqs, float* out, int E, int dim, float scale);
+F5E_API int f5e_sinus_embed(f5e_stream st, const float* t, const float* freqs, float* out, int E, int dim, float scale);
 /* out[n][i] = (cos, sin)(n * inv_freq[i])   (x_transformers RotaryEmbedding.forward_from_seq_len) */
-int f5e_rope_table(f5e_stream st, const float* inv_freq, float* out, int N, int half);
+F5E_API int f5e_rope_table(f5e_stream st, const float* inv_freq, float* out, int N, int half);
 /* out[b][n] = (table[ids[b][n]] + pos[min(n, max_pos-1)]) * keep[b][n]   (backbones/dit.py:68-80).  table f32
  * [table_rows][TD]; an id outside [0, table_rows) is clamped (nn.Embedding raises IndexError there: the host side checks
  * ids that start on the host, the clamp only keeps device-resident garbage from reading outside the table). */
-int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const float* pos, const float* keep, float* out,
+F5E_API int f5e_text_gather(f5e_stream st, const int* ids, const float* table, const float* pos, const float* keep, float* out,
                     int B, int N, int TD, int max_pos, int table_rows);
 /* v = p0 | p0 + (p0 - p1) w0 | w0 (p2 - p1) + w1 (p1 - p0) + p0   (mode 0 | 1 | 2; p_k = pred + k * branch_stride);
  * dst = base + coef[*eval_ptr] * v; traj (optional) gets a copy.   (model/cfm.py:447, :187, :310 + Euler/midpoint)
  * done_ctr (optional, one zero-initialised u32): the last workgroup to finish does ++*eval_ptr and re-zeroes it. */
-int f5e_ode_update(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+F5E_API int f5e_ode_update(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
                    const float* base, float* dst, float* traj, const float* coef, int* eval_ptr, unsigned* done_ctr,
                    long long n);
 /* Same, with the trajectory row picked on the device: traj row (*eval_ptr + 1) / traj_div of [rows][traj_stride] floats
  * (euler: traj_div 1; midpoint's second stage: 2), so a captured step needs no per-step copy.  traj_stride 0 = plain. */
-int f5e_ode_update_traj(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
+F5E_API int f5e_ode_update_traj(f5e_stream st, const float* pred, long long branch_stride, int mode, float w0, float w1,
                         const float* base, float* dst, float* traj, long long traj_stride, int traj_div,
                         const float* coef, int* eval_ptr, unsigned* done_ctr, long long n);
-int f5e_advance_eval(f5e_stream st, int* eval_ptr);
+F5E_API int f5e_advance_eval(f5e_stream st, int* eval_ptr);
 /* out = mask ? cond : y   (cfm.py:476); mask u8 [rows], tensors f32 [rows][C] */
-int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
+F5E_API int f5e_stitch(f5e_stream st, const float* cond, const float* y, const unsigned char* mask, float* out, long long rows,
                int C);
-int f5e_cast_bf16(f5e_stream st, const float* x, void* y, long long n);
+F5E_API int f5e_cast_bf16(f5e_stream st, const float* x, void* y, long long n);
 /* y f32 = x bf16 (exact).  Used to rebuild the fused-AdaLN tables from the bf16 weights the MFMA kernels read. */
-int f5e_cast_f32(f5e_stream st, const void* x, float* y, long long n);
+F5E_API int f5e_cast_f32(f5e_stream st, const void* x, float* y, long long n);
 /* out = a x + b y + c  (y may be NULL).  (1 - t_inter) y0 + t_inter cond of duplicate_test (model/cfm.py:460-465). */
-int f5e_axpby(f5e_stream st, const float* x, const float* y, float* out, float a, float b, float c, long long n);
+F5E_API int f5e_axpby(f5e_stream st, const float* x, const float* y, float* out, float a, float b, float c, long long n);
 /* GumbelVectorQuantizer eval forward (model/modules.py:881-950): logits f32 [rows][ld] (groups * num_vars used) ->
  * targets i32 [rows][groups] (first maximal index), out f32 [rows][groups * var_dim] gathered from vars f32
  * [(combine_groups ? 1 : groups) * num_vars][var_dim]; stats (optional) f32[2] = (code_perplexity, prob_perplexity). */
-int f5e_vq_eval(f5e_stream st, const float* logits, int ld, const float* vars, int combine_groups, float* out,
+F5E_API int f5e_vq_eval(f5e_stream st, const float* logits, int ld, const float* vars, int combine_groups, float* out,
                 int* targets, float* stats, int rows, int groups, int num_vars, int var_dim);
 
 /* ---------------------------------------------------------------- mel / vocoder ------------------------------ */
 
 /* out[B][T][n_mels] = log(clamp(|STFT(wav)| . fb, 1e-5)), T = 1 + nw / hop, reflect-padded, centred (modules.py:75-101).
  * window f32 [1024]; twiddle f32 [512][2] = (cos, -sin)(2 pi k / 1024); fb f32 [513][n_mels]. */
-int f5e_stft_logmel(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+F5E_API int f5e_stft_logmel(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
                     const float* fb, float* out, int B, int n_fft, int hop, int n_mels);
 /* The same, bit for bit, with the filterbank handed over banded: filter m is non-zero on FFT bins [lo, lo + cnt) only
  * (fb_band i32 [n_mels][3] = lo, cnt, offset into fb_compact; fb_compact f32 [nnz <= 2048] = those weights, filter after
  * filter).  What MelSpec uses; the dense form above stays for arbitrary filterbanks. */
-int f5e_stft_logmel_banded(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+F5E_API int f5e_stft_logmel_banded(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
                            const float* fb_compact, const int* fb_band, int nnz, float* out, int B, int n_fft, int hop,
                            int n_mels);
 /* Vocos ISTFTHead tail: z f32 [B*T][ldz] (513 log-magnitudes | 513 phases) -> out f32 [B][hop * (T - 1)];
  * frames_ws f32 [B*T][1024] scratch. */
-int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, const float* twiddle, float* frames_ws,
+F5E_API int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, const float* twiddle, float* frames_ws,
                    float* out, int B, int T, int n_fft, int hop);
 
 /* ---------------------------------------------------------------- PPG extractor front ------------ */
@@ -229,18 +231,18 @@ int f5e_istft_head(f5e_stream st, const float* z, int ldz, const float* window, 
  * [f shift, f shift + win) of wav * in_scale (snip_edges), minus its mean, pre-emphasised (x[j] - preemph x[j-1], x[-1] = x[0]),
  * times window[win] (povey), zero-padded to 512, |rfft|^2 . fb[257][n_mels], log(max(., eps)).
  * out f32 [B][T][n_mels], T = 1 + (nw - win) / shift.  twiddle f32 [256][2] = (cos, -sin)(2 pi k / 512). */
-int f5e_kaldi_fbank(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
+F5E_API int f5e_kaldi_fbank(f5e_stream st, const float* wav, int nw, int ldw, const float* window, const float* twiddle,
                     const float* fb, float* out, int B, int win, int shift, int n_mels, float in_scale, float preemph,
                     float eps);
 /* y[r][c] = x[r][c] * sigmoid(x[r][C + c])   (F.glu over channels, ppg/wenet/transformer/convolution.py:119) */
-int f5e_glu(f5e_stream st, const float* x, int ldx, float* y, int ldy, long long rows, int C);
+F5E_API int f5e_glu(f5e_stream st, const float* x, int ldx, float* y, int ldy, long long rows, int C);
 /* Depthwise Conv1d(C, C, K, padding (K-1)/2, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [K][C];
  * keep (optional f32 [B][T], 0/1): frames with keep == 0 count as zeros (convolution.py:100-101).  Odd K <= 31. */
-int f5e_dwconv(f5e_stream st, const float* x, const float* w_t, const float* bias, const float* keep, float* y, int B,
+F5E_API int f5e_dwconv(f5e_stream st, const float* x, const float* w_t, const float* bias, const float* keep, float* y, int B,
                int T, int C, int K);
 /* y[r][k] = softmax_k(scale * x[r][k], k < len) for k < len, 0 for len <= k < ldy; len = kv_len[r / rows_per_seq] or L
  * (ppg/wenet/transformer/attention.py:75-87). */
-int f5e_softmax_rows(f5e_stream st, const float* x, int ldx, float* y, int ldy, const int* kv_len, long long rows,
+F5E_API int f5e_softmax_rows(f5e_stream st, const float* x, int ldx, float* y, int ldy, const int* kv_len, long long rows,
                      int rows_per_seq, int L, float scale);
 
 /* ---------------------------------------------------------------- fused DiT evaluation ----------------------- */
@@ -288,7 +290,6 @@ typedef struct f5e_dit_plan {
   float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
   const float* cd;                       /* [E][mod_rows][cd_stride] f32: per block c_qkv | d_qkv | c_ff1 | d_ff1 */
   int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
-  float* ln_rowstats;                    /* [S*N + 1][2] f32 workspace: finalized (mean, rstd) per row, large M only */
   /* batch-1 chains (fused AdaLN path): a few grid-tail workgroups of each block launch pull the weights of the launch after
    * next into the 256 MB Infinity Cache (the 646 MB of block weights cycle through it, so every GEMM otherwise streams
    * from HBM).  Pure performance hint: results never depend on it. */
@@ -301,41 +302,41 @@ typedef struct f5e_dit_plan {
  * need (ln_stats without fuse_ln, skip_* without w_skip) get size 0.  q, k and vt must be zero-filled once by the caller
  * (their pad rows are never written).  Host call, no kernel launch, no allocation. */
 enum { F5E_WS_H0 = 0, F5E_WS_H0_BF16, F5E_WS_C1, F5E_WS_X, F5E_WS_HN, F5E_WS_Q, F5E_WS_K, F5E_WS_VT, F5E_WS_AO, F5E_WS_FF,
-       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_LN_ROWSTATS, F5E_WS_COUNT };
+       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_COUNT };
 typedef struct f5e_dit_workspace {
   int n_pad;
   unsigned long long bytes[F5E_WS_COUNT];
   unsigned long long offset[F5E_WS_COUNT];
   unsigned long long total;
 } f5e_dit_workspace;
-int f5e_workspace_bytes(const f5e_dit_plan* shape, f5e_dit_workspace* out_host);
+F5E_API int f5e_workspace_bytes(const f5e_dit_plan* shape, f5e_dit_workspace* out_host);
 
 enum { F5E_OP_NONE = 0, F5E_OP_INPROJ = 1, F5E_OP_CONVPOS = 2, F5E_OP_LN = 3, F5E_OP_QKV = 4, F5E_OP_ATTN = 5,
        F5E_OP_OUT = 6, F5E_OP_FF1 = 7, F5E_OP_FF2 = 8, F5E_OP_FINAL = 9 };
 
 /* HIP-event timer: host-side helpers (these DO allocate / synchronise; they are not ops).  f5e_dit_forward records
  * one start/stop pair around every launch of plan->timer_op, on the stream the kernels are launched on. */
-int f5e_timer_create(int capacity, void** timer_out);
-int f5e_timer_destroy(void* timer);
-int f5e_timer_reset(void* timer);
-int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
-int f5e_timer_read_ops(void* timer, int* ops_out_host, int max_out, int* count_out_host); /* op class of each pair */
+F5E_API int f5e_timer_create(int capacity, void** timer_out);
+F5E_API int f5e_timer_destroy(void* timer);
+F5E_API int f5e_timer_reset(void* timer);
+F5E_API int f5e_timer_read(void* timer, float* ms_out_host, int max_out, int* count_out_host);
+F5E_API int f5e_timer_read_ops(void* timer, int* ops_out_host, int max_out, int* count_out_host); /* op class of each pair */
 
 #ifdef F5E_TOOLS
 /* Diagnostics, TOOLS build only (make -C f5e-tts_amd/csrc tools-lib -> libf5e_hip_tools.so; tools/convpos_time.py): while
  * buf != NULL, f5e_convpos / f5e_convpos_ln launch a build of their kernels that writes 8 timestamps per workgroup.  This is
  * process-wide mutable state, which is why the shipped libf5e_hip.so neither contains nor exports it. */
-void f5e_debug_convpos_trace(void* buf);
+F5E_API void f5e_debug_convpos_trace(void* buf);
 #endif
 
 /* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
-int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
+F5E_API int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
 
 /* ---------------------------------------------------------------- hipGraph capture --------------------------- */
-int f5e_graph_begin(f5e_stream st);
-int f5e_graph_end(f5e_stream st, void** graph_exec_out);
-int f5e_graph_launch(void* graph_exec, f5e_stream st);
-int f5e_graph_destroy(void* graph_exec);
+F5E_API int f5e_graph_begin(f5e_stream st);
+F5E_API int f5e_graph_end(f5e_stream st, void** graph_exec_out);
+F5E_API int f5e_graph_launch(void* graph_exec, f5e_stream st);
+F5E_API int f5e_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,9 @@
 """Parity of the HIP path at the FULL sizes of BASELINE.json's configs (C2..C5), each through its real caller:
 
   C2  F5TTS_v1_Base, batch 1, N_ref 188 / N 469, euler NFE 32, CFG 2, hipGraph loop + Vocos      -> vs the fp32 oracle
-  C3  F5TTS_v1_Base, batch 32 x (N_ref 375 / N 938), CFG 2, 4 Euler steps of the NFE-32 grid      -> every item vs its own
-      batch-1 run (size-independent property) and one item vs the fp32 oracle
+  C3  F5TTS_v1_Base, batch 32 x (N_ref 375 / N 938), CFG 2: (a) 4-step grid -> every item vs its own batch-1 run
+      (size-independent property) and one item vs the fp32 oracle; (b) the config's own NFE 32 -> four items vs batch 1 and
+      one item vs the fp32 oracle with the per-step trajectory check
   C4  eval_infer_batch.main() on three utterances of the C4 length mix (shortest / median / longest of the table: ~610 / 910 / 1390 frames), NFE 16 -> the written
       wavs vs a direct sample + decode (bit exact up to int16) and the shortest one vs the oracle's mel -> Vocos
   C5  configs/F5TTS_Small_PPG.yaml (dim 768, 18 blocks, PPG input, codebook keys), sample_vc, NFE 32 -> vs the fp32 oracle
@@ -107,6 +108,35 @@ def test_c3_batch32_items_equal_their_batch1_runs_and_the_oracle():
     ref_out, ref_traj = O.cfm_sample(sd, cfg, wav[i:i + 1], text[i:i + 1], None, **kw)
     check_trajectory(ftraj[:, i:i + 1], ref_traj, n_ref, "C3 item 17 vs oracle")
     assert rel_l2(full[i, n_ref:], ref_out[0, n_ref:]) < TOL_REL_L2
+
+
+def test_c3_full_nfe32_batch32_vs_batch1_and_oracle():
+    """BASELINE C3 at its OWN NFE: batch 32 x (N_ref 375 / N 938), euler NFE 32, CFG 2, sway -1 -- 60 032-row launches
+    through all 32 steps of the ping-pong GEMM / LDS attention / separate-LayerNorm path (reference model/cfm.py:349-482).
+    Four items against their batch-1 GPU runs at NFE 32 (size-independent property, the 64 x 64 GEMM + fused-AdaLN path)
+    and one item against the fp32 oracle at NFE 32 (~35 s of host CPU), with the per-step trajectory check."""
+    cfg, sd, dit, cfm = full_model()
+    B, n_ref, n = 32, 375, 938
+    wav, text = SY.synthetic_ref_wave(n_ref, batch=B), SY.synthetic_text_ids(n, batch=B)
+    kw = dict(duration=n, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
+    full, ftraj = cfm.sample(wav.cuda(), text, **kw)
+    assert full.shape == (B, n, 100) and ftraj.shape == (33, B, n, 100) and torch.isfinite(full).all()
+    worst = 0.0
+    for i in (0, 9, 17, 31):
+        one, _ = cfm.sample(wav[i:i + 1].cuda(), text[i:i + 1], **kw)
+        e = rel_l2(full[i, n_ref:], one[0, n_ref:])
+        worst = max(worst, e)
+        assert e < TOL_REL_L2, (i, e)
+        assert torch.equal(full[i, :n_ref], one[0, :n_ref])
+    print("C3 NFE 32: worst item-vs-batch-1 rel L2 %.3e" % worst)
+    i = 17
+    ref_out, ref_traj = O.cfm_sample(sd, cfg, wav[i:i + 1], text[i:i + 1], None, **kw)
+    assert torch.equal(ftraj[0, i:i + 1].cpu(), ref_traj[0])          # seeded CPU noise is bit-identical per item
+    check_trajectory(ftraj[:, i:i + 1], ref_traj, n_ref, "C3 NFE 32 item 17 vs oracle")
+    gen, rgen = full[i, n_ref:].cpu(), ref_out[0, n_ref:]
+    print("C3 NFE 32: item 17 final rel L2 %.3e" % rel_l2(gen, rgen))
+    assert rel_l2(gen, rgen) < TOL_REL_L2
+    assert float((gen - rgen).abs().max()) < TOL_MAXABS_OF_RANGE * float(rgen.max() - rgen.min())
 
 
 def test_c5_small_ppg_depth18_sample_vc_vs_oracle():

@@ -333,6 +333,35 @@ def test_sampler_flags_and_edges():
         assert rel_l2(o, ro) < 1.5e-2, extra
 
 
+def test_out_of_range_token_id_raises_like_nn_embedding():
+    """A vocabulary / checkpoint mismatch must raise, not produce audio: nn.Embedding raises IndexError on an id outside the
+    table (reference backbones/dit.py:55-68, ids shifted by +1, truncated to the sequence length first); the HIP gather
+    only clamps.  Both entry points: CFM.sample (host or device ids) and DiT.sample with host ids."""
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    cond = torch.randn(1, 40, 100, generator=torch.Generator().manual_seed(3))
+    good = torch.randint(0, 300, (1, 30), generator=torch.Generator().manual_seed(4))
+    bad = good.clone()
+    bad[0, 7] = 300                                   # table has text_num_embeds + 1 = 301 rows; 300 + 1 is outside
+    kw = dict(duration=64, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1)
+    cfm.sample(cond.cuda(), good, **kw)
+    for ids in (bad, bad.cuda()):
+        with pytest.raises(IndexError):
+            cfm.sample(cond.cuda(), ids, **kw)
+    x = torch.randn(1, 64, 100).cuda()
+    c64 = torch.nn.functional.pad(cond, (0, 0, 0, 24)).cuda()
+    t = torch.tensor(0.3)
+    dit.clear_cache()
+    dit.sample(x, c64, good, None, t, False, False, False)
+    dit.clear_cache()
+    with pytest.raises(IndexError):
+        dit.sample(x, c64, bad, None, t, False, False, False)
+    dit.clear_cache()
+    late = torch.cat([good, torch.full((1, 40), -1)], 1)
+    late[0, 66] = 5000                                # beyond the 64 frames: truncated away before the lookup (dit.py:59)
+    dit.sample(x, c64, late, None, t, False, False, False)
+
+
 def test_max_duration_4096_single_forward():
     """Longest supported sequence (max_duration = 4096 frames, reference cfm.py:361): one DiT evaluation, 2 blocks."""
     cfg = O.DiTConfig(**SMALL)

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in f5e_abi.h but not exported"
         assert n in _C.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.f5e_abi_version() == 1
+    assert lib.f5e_abi_version() == _C.ABI_VERSION == 2
     assert lib.f5e_last_error() == b""
 
 
@@ -56,7 +56,7 @@ def test_workspace_bytes_planner():
     assert w.n_pad == n_pad
     want = dict(h0=M * 1024 * 4, h0_bf16=M * 1024 * 2, c1=M * 1024 * 2, x=M * 1024 * 4, hn=M * 1024 * 2,
                 q=2 * 16 * n_pad * 64 * 2, k=2 * 16 * n_pad * 64 * 2, vt=2 * 16 * n_pad * 64 * 2, ao=M * 1024 * 2,
-                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0, ln_rowstats=0)
+                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0)
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got == want
     end = 0
@@ -68,7 +68,6 @@ def test_workspace_bytes_planner():
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == 0
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got["ln_stats"] == M * 16 * 2 * 4 and got["skip_res"] == got["skip_tmp"] == M * 1024 * 4
-    assert got["ln_rowstats"] == (M + 1) * 8
     p.N = 0
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == -1 and b"workspace_bytes" in lib.f5e_last_error()
 
@@ -355,6 +354,53 @@ def test_bench_c4_partition_and_reductions_world2_gloo(tmp_path):
     assert all(600 < t <= 2048 and 0 < rr < t for rr, t in utts)
 
 
+def _run_bench(argv, env_extra=None, launcher=None):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + argv
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher) must BE a two-rank job: it starts torch.distributed.run as a child process
+    (reference: `accelerate launch`, eval/eval_infer_batch.sh:4-6) and relays exactly one JSON line whose n_gpus /
+    world_size / per-rank records show two ranks; the fixed-total C4 leg splits every utterance onto exactly one rank.
+    --stub: gloo and a sleep instead of RCCL and the GPU pass (the launch / partition / reduction code is the same)."""
+    pr = _run_bench(["--gpus", "2", "--stub", "--steps", "4", "--warmup", "1", "--c4-total", "21"])
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, pr.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == line["world_size"] == 2 and line["backend"] == "gloo" and line["data"] == "stub"
+    assert len(line["per_rank_frames"]) == len(line["per_rank_seconds"]) == 2
+    assert line["per_rank_frames"][0] == line["per_rank_frames"][1] == 4 * 469          # weak scaling: same work per rank
+    c4 = line["scaling_c4"]
+    assert c4["scaling"] == "strong" and c4["utterances"] == 21 and sum(c4["per_rank_utterances"]) == 21
+    from f5e_tts_amd.eval.eval_infer_batch import c4_work_list
+    assert sum(c4["per_rank_frames"]) == sum(t for _, t in c4_work_list(os.path.join(GOLD, "c4_durations.csv"), 21))
+    assert abs(c4["per_rank_utterances"][0] - c4["per_rank_utterances"][1]) <= 1
+
+
+def test_bench_under_the_drivers_launcher_and_world_mismatch():
+    """The driver's own form (torch.distributed.run ... bench.py --gpus N) runs the ranks in place -- no second launch --
+    and a --gpus that disagrees with WORLD_SIZE is an error, not a silent one-rank run."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port)]
+    pr = _run_bench(["--gpus", "2", "--stub", "--steps", "3", "--warmup", "0", "--c4-total", "0"], launcher=launcher)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank_frames"]) == 2 and line["scaling_c4"] is None
+    bad = _run_bench(["--gpus", "4", "--stub"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
 def test_full_size_layouts_match_reference_including_codebook():
     """F5TTS_v1_Base and BASELINE config 5 (Small + PPG + Gumbel codebook) built from this package's yaml files have
     exactly the reference's state_dict names and shapes (tests/golden/layouts.json, written by the reference)."""
@@ -403,4 +449,38 @@ def test_every_environment_switch_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(v for v in used if f"`{v}`" not in doc)
     assert not missing, f"undocumented environment switches: {missing}"
-    assert len(used) >= 10
+    assert len(used) >= 6
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """include/f5e_abi.h promises no process-wide state: every getenv in csrc/ sits inside an F5E_TOOLS block (diagnostics
+    build), and the shipped libf5e_hip.so does not even import getenv."""
+    import subprocess
+    csrc = os.path.join(ROOT, "f5e-tts_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        stack = []          # one entry per open #if: True while inside the F5E_TOOLS branch of an #ifdef F5E_TOOLS
+        for ln in open(os.path.join(csrc, f)):
+            t = ln.strip()
+            if t.startswith("#if"):
+                stack.append(t.startswith("#ifdef F5E_TOOLS"))
+            elif t.startswith("#else") and stack:
+                stack[-1] = False
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            if "getenv(" in ln and not t.startswith("//"):
+                assert any(stack), f"{f}: getenv outside an F5E_TOOLS block: {t}"
+    und = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "f5e-tts_amd", "libf5e_hip.so")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+
+
+def test_library_exports_only_the_declared_c_abi():
+    """-fvisibility=hidden + the linker version script: the dynamic symbol table of libf5e_hip.so holds exactly the functions
+    f5e_abi.h declares -- no C++-mangled internals, no kernels, no per-unit markers."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "f5e-tts_amd", "libf5e_hip.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))

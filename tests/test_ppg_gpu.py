@@ -97,6 +97,33 @@ def test_default_size_conformer_vs_oracle(B, T):
     assert rel_l2(logits.view(B, T2, -1).cpu()[valid], ref_logits.view(B, T2, -1)[valid]) < 5e-4
 
 
+def test_single_padded_utterance_is_masked_like_the_reference():
+    """B = 1 with speech_lengths < T: the reference BaseEncoder builds its masks from xs_lens for a single padded utterance
+    too (padded keys masked in attention, padded frames zeroed in the conv module; ppg/wenet/transformer/encoder.py) --
+    against the oracle, and against the same padded utterance as the SHORT item of a batch of two (the B > 1 path that the
+    reference fixture pins)."""
+    from f5e_tts_amd.ppg import ConformerPPG
+    g = torch.Generator().manual_seed(9)
+    m = ConformerPPG(80, 40, 64, 4, 128, 2, 15, global_cmvn=(torch.zeros(80), torch.ones(80)))
+    sd = seeded_state(m, 13)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    T, n = 181, 120
+    feats = 3.0 * torch.randn(1, T, 80, generator=g) + 6.0      # the padding is NOT zero: an unmasked path would show
+    lens = torch.tensor([n])
+    ref, _ = P.asr_extract(sd, feats, lens, heads=4)
+    ppg, _ = m.extract(feats.cuda(), lens)
+    nv = int((torch.arange(0, T - 2, 2) < n).sum())
+    e = rel_l2(ppg.cpu()[0, :nv], ref[0, :nv])
+    print("B=1 padded: ppg rel L2 %.2e over %d valid frames" % (e, nv))
+    assert e < 5e-4
+    full = 3.0 * torch.randn(1, T, 80, generator=g) + 6.0
+    both, _ = m.extract(torch.cat([full, feats]).cuda(), torch.tensor([T, n]))
+    assert rel_l2(both[1, :nv], ppg[0, :nv]) < 1e-5
+    unmasked, _ = m.extract(feats.cuda(), torch.tensor([T]))
+    assert rel_l2(unmasked[0, :nv], ppg[0, :nv]) > 1e-3           # the mask matters for this input
+
+
 def test_kaldi_fbank_kernel_vs_oracle():
     from f5e_tts_amd.ppg import kaldiFbank
     g = torch.Generator().manual_seed(3)

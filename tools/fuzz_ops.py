@@ -35,19 +35,17 @@ def c(*xs):
 def draw():
     k = rng.random()
     if k < 0.2:
-        hint = c(0, 1, 2, 3, 9, 89, 119)
+        hint = c(0, 1, 2, 3, 9)
         K = 64 * r(1, 6) if hint < 9 else 64 * r(2, 6)
         return T.test_gemm_bf16_bias, (r(1, 700), 4 * r(1, 200), K, hint)
     if k < 0.45:
-        hint = c(0, 9, 89, 119, 35, 45)
+        hint = c(0, 9)
         rps = r(1, 400)
         S = r(1, 5)
         K = 64 * r(2, 6) if hint >= 9 else 64 * r(1, 6)
-        if hint in (35, 45):
-            K = 128 * r(1, 4)
         return T.test_gemm_bf16_gate_residual, (S * rps, 4 * r(1, 160), K, rps, hint)
     if k < 0.7:
-        hint = c(0, 9, 89, 119)
+        hint = c(0, 9)
         H = r(1, 12)
         return T.test_qkv_rope, (r(1, 4), r(1, 420), H, r(0, H), 64 * r(2, 5), hint)
     if k < 0.85:
@@ -60,7 +58,7 @@ def draw():
         return T.test_convpos, (r(1, 3), r(1, 500), G * c(16, 32, 48, 64), G)
     k2 = rng.random()
     if k2 < 0.3:
-        hint = c(0, 9, 35, 45)
+        hint = c(0, 9)
         N = r(20, 330)
         return T.test_fused_adaln_chain, (r(1, 3), N, c(256, 512, 768, 1024), 4 * r(8, 400), c(0.0, 0.3, 0.7), N >= 30 and c(False, True), hint)
     if k2 < 0.5:

@@ -19,7 +19,7 @@ def timeit(fn, reps=NW * 2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
-hints = [int(h) for h in sys.argv[2].split(',')] if len(sys.argv) > 2 else [21, 31, 22, 32, 42, 23, 33, 43]  # tile + 10*stages
+hints = [int(h) for h in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 3, 9]  # tile family (f5e_abi.h)
 ONLY = os.environ.get("ONLY", "QKV,OUT,FF1,FF2").split(",")
 for name, N, K in (("QKV", 3072, 1024), ("OUT", 1024, 1024), ("FF1", 2048, 1024), ("FF2", 1024, 2048)):
     if name not in ONLY:

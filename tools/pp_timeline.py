@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of the 256x256 ping-pong GEMM (tools build, DBG 7 = tile_hint 79).  GPU box only.
+"""Per-workgroup timeline of the 256x256 ping-pong GEMM (tools build: launches stamp while F5E_PP_TRACE names a buffer).  GPU box only.
 
     make -C f5e-tts_amd/csrc tools-lib && python tools/pp_timeline.py [M] [ff1|out]
 
@@ -20,7 +20,7 @@ from f5e_tts_amd import ops  # noqa: E402
 BF = torch.bfloat16
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 60032
 kind = sys.argv[2] if len(sys.argv) > 2 else "ff1"
-HINT = int(sys.argv[3]) if len(sys.argv) > 3 else 79   # 99: A from a cache-resident window, 109: A and out
+HINT = 9
 N, K = {"ff1": (2048, 1024), "qkv": (3072, 1024), "ff2": (1024, 2048)}.get(kind, (1024, 1024))
 a = torch.randn(M, K, device="cuda").to(BF)
 ws = [(torch.randn(N, K, device="cuda") / math.sqrt(K)).to(BF) for _ in range(4)]
@@ -59,7 +59,7 @@ raw = trace.cpu()
 t = raw[:256 * 64].view(256, 16, 4).double() * 0.01   # us
 cyc = raw[256 * 64:].view(256, 16, 2).double()
 t0 = t[:, 0, 0][t[:, 0, 0] > 0].min()
-print(f"hint {HINT} {kind} M={M} N={N} K={K}: {e0.elapsed_time(e1) * 1e3:.1f} us, stagger={os.environ.get('F5E_PP_STAGGER', '1')}")
+print(f"{kind} M={M} N={N} K={K}: {e0.elapsed_time(e1) * 1e3:.1f} us")
 print("round  n_wg  entry->landed  K loop  epilogue   loop-end spread (p5..p95 of t - t0)")
 for r in range(16):
     m = t[:, r, 3] > 0
