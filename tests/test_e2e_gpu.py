@@ -446,6 +446,38 @@ def test_concurrent_sample_calls_from_two_threads():
             assert torch.equal(a, b)
 
 
+def test_threads_cycling_through_more_shapes_than_the_loop_cache_holds():
+    """Two threads, each sampling MORE distinct lengths than its per-thread cache of persistent loop states holds
+    (engine.LOOP_CACHE_ENTRIES), twice over: every call evicts a state while the other thread may be capturing.  Evicted
+    graphs are parked behind an event on the CALLER's stream (engine.retire_pending), never on a stream that captures, so
+    no capture is invalidated and every result equals the sequential one bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from f5e_tts_amd import engine as E
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    g = torch.Generator().manual_seed(17)
+    lengths = [64 + 3 * i for i in range(E.LOOP_CACHE_ENTRIES + 3)]
+    jobs = []
+    for i, n in enumerate(lengths):
+        cond = torch.randn(1, 30, 100, generator=g).cuda()
+        text = torch.randint(0, 300, (1, 8 + i % 5), generator=g)
+        jobs.append(dict(cond=cond, text=text, duration=n, steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=40 + i))
+    seq = [cfm.sample(**j)[0].clone() for j in jobs]
+
+    def worker(order):
+        return [(i, cfm.sample(**jobs[i])[0].clone()) for i in order for _ in range(2)]
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        res = list(ex.map(worker, [list(range(len(jobs))), list(reversed(range(len(jobs))))]))
+    torch.cuda.synchronize()
+    for out in res:
+        for i, o in out:
+            assert torch.equal(o, seq[i]), i
+    eng = dit.engine()
+    assert not getattr(eng._loops, "pending", None)          # this thread's evictions were parked, not left queued
+
+
 @pytest.mark.parametrize("ref_sr", [24000, 16000])
 def test_infer_cli_end_to_end(tmp_path, ref_sr):
     """infer_cli.main with the reference's flags: yaml arch -> load_model (EMA safetensors checkpoint) -> local Vocos ->

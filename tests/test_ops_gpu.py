@@ -43,7 +43,7 @@ def close(a, b, rtol, atol, what=""):
                                         (1, 64, 64, 0), (256, 256, 256, 1),
                                         # hint 9 = the 256x256 ping-pong kernel (auto-selected at large M)
                                         (938, 2048, 1024, 9), (700, 768, 512, 9), (300, 100, 128, 9), (256, 256, 128, 9),
-                                        (1300, 512, 2048, 9)])
+                                        (1300, 512, 2048, 9), (5000, 640, 192, 9)])
 def test_gemm_bf16_bias(ops, M, N, K, hint):
     a = torch.randn(M, K, generator=g(1)).to(BF)
     w = (torch.randn(N, K, generator=g(2)) / math.sqrt(K)).to(BF)
@@ -61,7 +61,7 @@ def test_gemm_bf16_bias(ops, M, N, K, hint):
 
 def test_gemm_bf16_identity_asymmetric(ops):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
-    for n, hints in ((128, (1, 2, 3)), (512, )):
+    for n, hints in ((128, (1, 2, 3)), (512, (1, 9))):
         a = torch.eye(n).to(BF)
         w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)  # exactly representable, asymmetric
         out = torch.empty(n, n, device="cuda")
@@ -130,9 +130,9 @@ def test_gate_residual_pingpong_lean_and_general_wave_tiles(ops, hint):
                                                      (3, 150, 12, 1, 768, 9),
                                                      # odd rows per sequence: V^T key groups start at odd offsets (2-byte pieces),
                                                      # a sequence boundary in every other wave tile
-                                                     (3, 131, 4, 1, 256, 9), (2, 257, 2, 2, 128, 9),
+                                                     (3, 131, 4, 1, 256, 9), (2, 257, 2, 2, 128, 9), (5, 199, 4, 4, 128, 9),
                                                      # heads not a multiple of 4: the last 256-column tile has waves past 3 * inner
-                                                     (2, 300, 6, 6, 128, 9), (2, 260, 10, 1, 128, 9), ])
+                                                     (2, 300, 6, 6, 128, 9), (2, 260, 10, 1, 128, 9), (2, 300, 6, 2, 128, 9)])
 def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     inner = H * 64
     n_pad = (N + 63) // 64 * 64
