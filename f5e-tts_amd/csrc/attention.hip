@@ -21,6 +21,23 @@
 // batch 1 (N = 469: 15 q-tiles x 32 (s, head) x 4 splits = 1920 waves).
 //   S^T = K . Q^T  (lane-local softmax statistics),  O^T = V^T . P^T with P taken from the S^T accumulator registers
 //   (cdna guide section 3 "An accumulator tile as the next MFMA's operand").
+//
+// Softmax arithmetic (round 3).  The kernel is bound by VALU issue, not by the matrix pipe: per 64-key step and wave the 16
+// MFMAs take 512 cycles, while round 2's softmax issued 33 v_exp (8 cycles each) + ~115 other VALU instructions (4 each) =
+// ~720 cycles (instruction histogram of the ISA).  Three changes take 54 of them out of every step:
+//   * Q arrives PRE-SCALED by log2(e) / sqrt(64) (f5e_gemm_bf16_qkv_rope folds it in before the bf16 rounding), so the MFMA
+//     result is the score in the log2 domain;
+//   * the running maximum enters through the accumulator: the first MFMA of a score chain takes C = minit, a 16-register
+//     tile holding -m_run (rewritten only when m_run moves), so p = exp2(acc) with no subtraction or multiply per element;
+//   * the maximum is not tracked per step at all.  Floating point is scale-free: any m_run gives the same O / l as long as
+//     nothing overflows, so m_run is the maximum of the query's FIRST step, and a later step only checks its row sums
+//     (already needed for l): a sum above 2^24 (some score more than ~19-24 octaves above m_run; inf / NaN included)
+//     sends the whole wave through the slow path -- recompute the step's scores from the operands still at hand, take the
+//     true maximum, rescale (l, O), move m_run.  p <= 2^24 keeps l and O far from the fp32 range (N <= 4096 keys) and the
+//     bf16 P operand as accurate as at any other scale.  Rare by construction: every pass through it raises a query's
+//     m_run by at least ~19 octaves.
+// Left per step: 32 v_exp, 32 v_add (row sums, half-wave partials: the two halves meet once at the end), 16 v_cvt_pk.
+#include <cstdlib>
 #include "f5e_common.h"
 
 namespace {
@@ -30,15 +47,127 @@ struct AttnArgs {
   bf16* o; int ldo;
   const int* kv_len;  // [S] or null (= rows_per_seq)
   int S, H, rows_per_seq, n_pad;
-  float scale_log2e;  // (1/sqrt(64)) * log2(e)
   int n_main;         // workgroups beyond it only prefetch (NSPLIT == 4 launches: 256 threads)
   F5ePrefetch pf;
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+constexpr float ROWSUM_LIMIT = 16777216.0f;   // 2^24, see the header: a step whose partial row sum exceeds it is redone
+
+// One 64-key step of the online softmax for a wave's 32 queries (lane = query ql, key half hh).
+//   qk(st, c): st[t] = c + (scores of keys 64 step + 32 t + ..., log2 domain), t = 0, 1 -- the 8 MFMAs of the step; may be
+//              called twice (slow path), so the K fragments must still be at hand
+//   on return st holds p = exp2(score - m_run) for the step's valid keys (0 for keys >= kv_len), l_val this lane's
+//   running partial row sum, (m_run, minit, oacc) updated if the running maximum moved.
+template <class QK>
+__device__ __forceinline__ void softmax_step(QK&& qk, bool first, bool partial, int key_base, int kv_len, f32x16 (&st)[2],
+                                             f32x16& minit, float& m_run, float& l_val, f32x16 (&oacc)[2]) {
+  auto mask_tail = [&]() {
+    // only the last step of a sequence: a real branch (the empty asm keeps hipcc from if-converting the block into 32
+    // compares + 32 selects executed on EVERY step)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key_base + t * 32 + (r & 3) + 8 * (r >> 2) >= kv_len) st[t][r] = -INFINITY;
+  };
+  if (!first) {
+    qk(st, minit);                       // score - m_run
+    if (partial) mask_tail();
+    // ONE accumulation chain on purpose: two independent chains are SLP-packed into v_pk_add_f32, which costs more issue
+    // time beside MFMAs than the two v_add_f32 it replaces (cdna guide, cycle constants: packed f32 VALU is an anti-lever)
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[t][r] = fast_exp2(st[t][r]);
+        rs += st[t][r];
+      }
+    if (__builtin_amdgcn_ballot_w64(!(rs <= ROWSUM_LIMIT)) == 0) {   // wave-uniform; NaN / inf fail the comparison
+      l_val += rs;
+      return;
+    }
+  }
+  // slow path: the first step of a query tile, or some query of the wave met scores far above its m_run
+  f32x16 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  qk(st, zero);
+  if (partial) mask_tail();
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+  mx = max_xor32(mx);                    // finite: every processed step holds at least one valid key
+  const float m_new = fmaxf(m_run, mx);
+  const float alpha = fast_exp2(m_run - m_new);   // first step: exp2(-inf) = 0
+  l_val *= alpha;
+  m_run = m_new;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; minit[r] = -m_new; }
+  float rs = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[t][r] = fast_exp2(st[t][r] - m_new);
+      rs += st[t][r];
+    }
+  l_val += rs;
+}
+
+// The unchecked step (see the header): scores arrive as score - m_run (C = minit), p = exp2 of them whatever their size --
+// no maximum, no comparison, no branch.  Half 0's exp2 / row-sum VALU work is written between the two halves' MFMAs and
+// half 1's between the P.V MFMAs, so that one wave keeps both pipes busy (a wave issues in order: VALU instructions placed
+// behind a block of MFMAs wait for all of them to ISSUE, i.e. for the matrix pipe).
+template <class KF, class VF>
+__device__ __forceinline__ void fast_step(KF&& kfrag, VF&& vfrag, const bf16x8 (&qf)[4], const f32x16& minit, float& l_val,
+                                          f32x16 (&oacc)[2]) {
+  f32x16 s0, s1;
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, 0), qf[0], minit, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, ks), qf[ks], s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(1, 0), qf[0], minit, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(1, ks), qf[ks], s1, 0, 0, 0);
+  float rs = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s0[r] = fast_exp2(s0[r]); rs += s0[r]; }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (bf16)s0[8 * s + j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(0, s, dt), pf, oacc[dt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s1[r] = fast_exp2(s1[r]); rs += s1[r]; }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (bf16)s1[8 * s + j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(1, s, dt), pf, oacc[dt], 0, 0, 0);
+  }
+  l_val += rs;
+}
+
+// true when this lane's row sum and output accumulators are all finite (inf and NaN fail `<=`)
+__device__ __forceinline__ bool accum_finite(float l_val, const f32x16 (&oacc)[2]) {
+  float mag = fabsf(l_val);   // a SUM, not a maximum: fmaxf drops NaNs, an addition keeps them (and infinities)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mag += fabsf(oacc[0][r]) + fabsf(oacc[1][r]);
+  return mag <= 3.0e38f;
+}
+
 template <int NSPLIT>
-__global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NSPLIT * 64, 2) void attn_fwd_kernel(AttnArgs a) {   // 2 waves per SIMD: <= 256 VGPRs
   // merge buffers: per extra wave, per lane: 32 O values + m + l
   __shared__ __attribute__((aligned(16))) float red[(NSPLIT > 1 ? NSPLIT - 1 : 1) * 64 * 34];
 
@@ -93,16 +222,12 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
     }
   };
 
-  f32x16 oacc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-
-  int t64 = wave;
-  if (t64 < ntiles) load_tile(t64);
-  while (t64 < ntiles) {
-    // current tile's fragments move to compute registers; the next tile's loads are issued before the MFMAs
-    bf16x8 ck[2][4], cv[2][2][2];
+  f32x16 oacc[2], minit;
+  float m_run, l_val;
+  bf16x8 ck[2][4], cv[2][2][2];   // the current step's fragments (kf / vf already hold the next step's)
+  int t64;
+  // current tile's fragments move to compute registers; the next tile's loads are issued before the MFMAs
+  auto advance = [&]() -> int {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -115,61 +240,29 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
     const int cur = t64;
     t64 += NSPLIT;
     if (t64 < ntiles) load_tile(t64);
-
-    // ---- S^T: st[t][reg] = score(key = 64 cur + 32 t + (reg&3) + 8 (reg>>2) + 4 hh, query = ql) ----
+    return cur;
+  };
+  auto pass_begin = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; minit[r] = 0.f; }
+    m_run = -INFINITY;
+    l_val = 0.f;
+    t64 = wave;
+    if (t64 < ntiles) load_tile(t64);
+  };
+  auto checked_tile = [&](bool first) {   // row sums checked against ROWSUM_LIMIT, running maximum moved when needed
+    const int cur = advance();
+    // ---- S^T: st[t][reg] = score(key = 64 cur + 32 t + (reg&3) + 8 (reg>>2) + 4 hh, query = ql), log2 domain ----
     f32x16 st[2];
+    auto qk = [&](f32x16 (&d)[2], const f32x16& c) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t) {
+        d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck[t][0], qf[0], c, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck[t][ks], qf[ks], st[t], 0, 0, 0);
-    }
-
-    // ---- online softmax (log2 domain) ----
-    const int key_base = cur * 64 + 4 * hh;
-    const bool partial = (cur * 64 + 64 > kv_len);
-    // The softmax VALU work (32 scores per lane and tile), not the MFMAs, bounds this kernel: the maximum is taken over
-    // the raw scores (the scale is positive), scale and subtraction fold into one fma in front of exp2, and the running
-    // maximum is only moved -- with the 32-multiply rescale of the accumulators -- when some query of the wave gained more
-    // than 2^8 on it: p <= 256 keeps fp32 sums and the bf16 P operand as accurate as before, and (m, l, O) stay
-    // consistent, so the final O / l is unchanged mathematically.
-    if (partial) {
-      // only the last tile of a sequence: a real branch (the empty asm keeps hipcc from if-converting the block into 32
-      // compares + 32 selects executed on EVERY tile)
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key_base + t * 32 + (r & 3) + 8 * (r >> 2) >= kv_len) st[t][r] = -INFINITY;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-    mx = max_xor32(mx) * a.scale_log2e;           // finite: every processed tile holds at least one valid key
-    const bool jump = mx - m_run > 8.0f;          // first tile: m_run = -inf
-    if (__builtin_amdgcn_ballot_w64(jump) != 0) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);  // first tile: exp2(-inf) = 0
-      l_run *= alpha;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-    }
-    float rs = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(__builtin_fmaf(st[t][r], a.scale_log2e, -m_run));
-        st[t][r] = p;
-        rs += p;
+        for (int ks = 1; ks < 4; ++ks) d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck[t][ks], qf[ks], d[t], 0, 0, 0);
       }
-    l_run += add_xor32(rs);
-
+    };
+    softmax_step(qk, first, cur * 64 + 64 > kv_len, cur * 64 + 4 * hh, kv_len, st, minit, m_run, l_val, oacc);
     // ---- O^T += V^T . P^T ; k-step (t, s): accumulator regs 8s..8s+7 of st[t] are exactly the B fragment ----
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -182,8 +275,28 @@ __global__ __launch_bounds__(NSPLIT * 64) void attn_fwd_kernel(AttnArgs a) {
         for (int dt = 0; dt < 2; ++dt)
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv[t][s][dt], pf, oacc[dt], 0, 0, 0);
       }
+  };
+
+  // Fast pass (see attn_fwd_lds_kernel below for the same structure): this wave's first step establishes m_run, its further
+  // FULL steps run unchecked, a partial last step (the sequence's last tile) is checked again; the accumulators are
+  // inspected once at the end and the wave repeats its steps in the checked form if anything overflowed.
+  pass_begin();
+  if (t64 < ntiles) checked_tile(true);
+  const int nfull = (ntiles * 64 > kv_len) ? ntiles - 1 : ntiles;   // steps without a key mask
+  while (t64 < nfull) {
+    advance();
+    auto kfrag = [&](int t, int ks) { return ck[t][ks]; };
+    auto vfrag = [&](int t, int s, int dt) { return cv[t][s][dt]; };
+    fast_step(kfrag, vfrag, qf, minit, l_val, oacc);
+  }
+  if (t64 < ntiles) checked_tile(false);
+  if (__builtin_amdgcn_ballot_w64(!accum_finite(l_val, oacc)) != 0) {   // wave-uniform; waves are independent until the merge
+    pass_begin();
+    bool first = true;
+    while (t64 < ntiles) { checked_tile(first); first = false; }
   }
 
+  float l_run = add_xor32(l_val);   // the two key halves of a query meet once, here
   // ---- merge the NSPLIT partial results (same queries, disjoint keys) ----
   // red: per extra wave [8 quads][64 lanes] f32x4 (lane-contiguous: conflict-free ds_write/read_b128) + [64 lanes] (m, l)
   if (NSPLIT > 1) {
@@ -306,74 +419,51 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
     }
   };
 
-  f32x16 oacc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-  float m_run = -INFINITY, l_val = 0.f;
+  f32x16 oacc[2], minit;
+  float m_run, l_val;
 
-  if (ntiles > 0) stage(0, 0);
-  if (NST > 2 && ntiles > 1) stage(1, 1);
+  // Ring bookkeeping of one 64-key step: wait until tile t64 has landed (NST - 2 younger tiles of 4 DMAs each may stay in
+  // flight) and every wave is done reading tile t64 - 1, stage tile t64 + NST - 1, return the slot of tile t64.
   int buf = 0, nbuf = NST - 1;
-  for (int t64 = 0; t64 < ntiles; ++t64) {
-    // tile t64 landed (NST - 2 younger tiles of 4 DMAs each may stay in flight), every wave done reading tile t64 - 1
-    if (NST > 2 && t64 + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  auto tile_begin = [&](int t64) -> const char* {
+    const int young = min(NST - 2, ntiles - 1 - t64);   // tiles staged after t64 that may stay in flight
+    if (young >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (young == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t64 + NST - 1 < ntiles) stage(nbuf, t64 + NST - 1);
     const char* Ks = smem + buf * TILE_BYTES;
+    buf = (buf == NST - 1) ? 0 : buf + 1;
+    nbuf = (nbuf == NST - 1) ? 0 : nbuf + 1;
+    return Ks;
+  };
+  auto pass_begin = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; minit[r] = 0.f; }
+    m_run = -INFINITY;
+    l_val = 0.f;
+    buf = 0;
+    nbuf = NST - 1;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+      if (t < ntiles) stage(t, t);
+  };
+  // K fragment (half t, ks) / V fragment (half t, s16 = s, dt) of the tile at Ks: 1 KiB each, lane-linear
+  auto checked_tile = [&](int t64) {   // row sums checked against ROWSUM_LIMIT, running maximum moved when needed
+    const char* Ks = tile_begin(t64);
     const char* Vs = Ks + 8192;
-
     f32x16 st[2];
+    // the K tile stays in its ring slot until the next step's barrier: the slow path may read it again
+    auto qk = [&](f32x16 (&d)[2], const f32x16& c) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16);
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
-      }
-    }
-    const int key_base = t64 * 64 + 4 * hh;
-    const bool partial = (t64 * 64 + 64 > kv_len);
-    // same softmax as attn_fwd_kernel: raw maximum, scale folded into the fma, running maximum moved lazily (> 2^8)
-    if (partial) {
-      // only the last tile of a sequence: a real branch (the empty asm keeps hipcc from if-converting the block into 32
-      // compares + 32 selects executed on EVERY tile)
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key_base + t * 32 + (r & 3) + 8 * (r >> 2) >= kv_len) st[t][r] = -INFINITY;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-    mx = max_xor32(mx) * a.scale_log2e;
-    const bool jump = mx - m_run > 8.0f;
-    if (__builtin_amdgcn_ballot_w64(jump) != 0) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      l_val *= alpha;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = fast_exp2(__builtin_fmaf(st[t][r], a.scale_log2e, -m_run));
-    {
-      float rs = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs += st[t][r];
-      l_val += add_xor32(rs);
-    }
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 kf = *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16);
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? c : d[t], 0, 0, 0);
+        }
+    };
+    softmax_step(qk, t64 == 0, t64 * 64 + 64 > kv_len, t64 * 64 + 4 * hh, kv_len, st, minit, m_run, l_val, oacc);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -383,18 +473,36 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[t][8 * s + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          // V fragment (tile t, s16 = s, dt): index ((t*2 + s)*2 + dt), each 1 KiB, lane-linear
           const bf16x8 vf = *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + ql * 32 + hh * 16);
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
         }
       }
-    buf = (buf == NST - 1) ? 0 : buf + 1;
-    nbuf = (nbuf == NST - 1) ? 0 : nbuf + 1;
+  };
+
+  // Fast pass: the first step establishes m_run (checked form), every further FULL step runs unchecked (fast_step: no
+  // maximum, no comparison, no branch -- ONE code path in the loop body, so nothing is copied between register sets at a
+  // join), a partial last step (key mask) takes the checked form again.
+  pass_begin();
+  if (ntiles > 0) checked_tile(0);
+  const int nfull = (ntiles > 0 && ntiles * 64 > kv_len) ? ntiles - 1 : ntiles;   // steps without a key mask
+  for (int t64 = 1; t64 < nfull; ++t64) {
+    const char* Ks = tile_begin(t64);
+    const char* Vs = Ks + 8192;
+    auto kfrag = [&](int t, int ks) { return *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16); };
+    auto vfrag = [&](int t, int s, int dt) { return *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + ql * 32 + hh * 16); };
+    fast_step(kfrag, vfrag, qf, minit, l_val, oacc);
+  }
+  if (nfull < ntiles && ntiles > 1) checked_tile(ntiles - 1);
+  // Nothing was compared on the way: if ANY query of the workgroup overflowed (inf / NaN in l or O), every wave repeats
+  // the pass in the checked form (the K / V ring is filled cooperatively).
+  if (__syncthreads_or(!accum_finite(l_val, oacc))) {
+    pass_begin();
+    for (int t64 = 0; t64 < ntiles; ++t64) checked_tile(t64);
   }
 
+  const float l_run = add_xor32(l_val);   // the two key halves of a query meet once, here
   const int q_row = (qb * 4 + wave) * 32 + ql;
   if (q_row < a.rows_per_seq) {
-    const float l_run = l_val;
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     bf16* op = a.o + ((size_t)seq * a.rows_per_seq + q_row) * a.ldo + head * 64 + 4 * hh;
 #pragma unroll
@@ -419,13 +527,24 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
   AttnArgs a{};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o; a.ldo = ldo;
   a.kv_len = kv_len; a.S = S; a.H = H; a.rows_per_seq = rows_per_seq; a.n_pad = n_pad;
-  a.scale_log2e = 0.125f * 1.4426950408889634f;
   const int grid = ((rows_per_seq + 31) / 32) * H * S;
   a.n_main = grid;
   // Large problems: K/V shared through LDS by 128-query workgroups (splits = -1 forces it, 0 picks it when the
   // LDS-free kernel would already have >= 8 waves per CU without any KV split)
   if (splits == -1 || (splits == 0 && grid >= 8192)) {
     const int g128 = ((rows_per_seq + 127) / 128) * H * S;
+#ifdef F5E_TOOLS
+    // tools build only (tools/attn_time.py): ring depth / occupancy variants for A/B timing on one box
+    static const int variant = getenv("F5E_ATTN_VARIANT") ? atoi(getenv("F5E_ATTN_VARIANT")) : 0;
+    if (variant == 33) {
+      static F5eDeviceOnce once33;
+      hipLaunchKernelGGL((attn_fwd_lds_kernel<3, 3>), dim3(g128), dim3(256), 3 * 16384, st, a);
+    } else if (variant == 23) {
+      hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 3>), dim3(g128), dim3(256), 2 * 16384, st, a);
+    } else if (variant == 42) {
+      hipLaunchKernelGGL((attn_fwd_lds_kernel<4, 2>), dim3(g128), dim3(256), 4 * 16384, st, a);
+    } else
+#endif
     hipLaunchKernelGGL((attn_fwd_lds_kernel<2, 4>), dim3(g128), dim3(256), 2 * 16384, st, a);
     F5E_LAUNCH_CHECK("flash_attn_lds");
     return F5E_OK;

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
             v[2] = x2 * cs[2] - x3 * cs[3];
             v[3] = x3 * cs[2] + x2 * cs[3];
           }
+          if (qkv_which == 0) v *= a.q_scale;   // softmax scale and log2(e), folded in here (attention.hip)
           // [tile = pos/32][ks = d/16][pos%32][(d/8)%2][d%8]
           const int off = (pos >> 5) * 2048 + (pos & 31) * 16 + (d >> 4) * 512 + ((d >> 3) & 1) * 8 + (d & 7);
           *(bf16x4*)(qkv_base + (size_t)seq * qkv_seq_stride + off) = f2bf4(v[0], v[1], v[2], v[3]);
@@ -605,6 +606,7 @@ int f5e_gemm_bf16_qkv_rope_pf(hipStream_t st, const void* A, int lda, const void
   a.q = (bf16*)q; a.k = (bf16*)k; a.vt = (bf16*)vt; a.n_pad = n_pad; a.heads = heads; a.rope_heads = rope_heads;
   a.cos_sin = cos_sin; a.rows_per_seq = rows_per_seq;
   a.qn_w = q_norm_w; a.kn_w = k_norm_w; a.qk_eps = 1e-6f;
+  a.q_scale = 0.125f * 1.4426950408889634f;
   F5E_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "gemm_bf16_qkv_rope: q and k norm weights go together");
   if (int e = check_common(a)) return e;
   F5E_REQUIRE(q && k && vt && cos_sin, "gemm_bf16_qkv_rope: null output/table");

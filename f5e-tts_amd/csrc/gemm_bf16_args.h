@@ -33,6 +33,7 @@ struct GemmArgs {
   int n_pad; int heads; int rope_heads;
   const float* cos_sin;  // [rows_per_seq][32][2]
   const float* qn_w; const float* kn_w; float qk_eps;  // optional RMSNorm over the head dim of q / k (qk_norm)
+  float q_scale;         // factor folded into q after RoPE, before the bf16 rounding: log2(e) / sqrt(64) (attention.hip)
   unsigned long long* trace;  // diagnostics builds only (tools/gemm_trace.hip, tools/pp_timeline.py): per-workgroup timeline
   // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
   //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),

@@ -77,6 +77,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
           v[2] = x2 * cs[2] - x3 * cs[3];
           v[3] = x3 * cs[2] + x2 * cs[3];
         }
+        if (which == 0) v *= a.q_scale;   // softmax scale and log2(e), folded into q (attention.hip)
         const size_t sh = (size_t)seq * a.heads + head;
         // fragment-major layouts consumed by attention.hip (index maps documented there)
         const int tile = pos >> 5, pr = pos & 31;

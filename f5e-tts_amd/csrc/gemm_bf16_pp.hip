@@ -299,6 +299,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
       bf16* base = (which == 0 ? a.q : a.k) + (size_t)head * a.n_pad * 64;
       const bool rope_on = head < a.rope_heads;
       const float* qk_w = a.qn_w ? (which == 0 ? a.qn_w : a.kn_w) : nullptr;
+      const float qsc = which == 0 ? a.q_scale : 1.0f;
       f32x4 bq[4], wq[4];
       int csoff[4];
 #pragma unroll
@@ -345,6 +346,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& a, char* smem, f32x4
             o[2] = v[i][2] * cs[2] - v[i][3] * cs[3];
             o[3] = v[i][3] * cs[2] + v[i][2] * cs[3];
           }
+          o *= qsc;   // q only: softmax scale and log2(e) (attention.hip); 1 for k
           *(bf16x4*)(reg + i * 4096 + r * 32 + ((fq ^ xr) << 3)) = f2bf4(o[0], o[1], o[2], o[3]);
         }
       }

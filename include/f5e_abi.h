@@ -68,6 +68,8 @@ F5E_API int f5e_gemm_bf16_gate_residual(f5e_stream st, const void* A, int lda, c
  * (rows: q | k | v).  Outputs: q, k [S][heads][n_pad][64] bf16, vt [S][heads][64][n_pad] bf16 (V transposed).
  * cos_sin: [rows_per_seq][32][2] f32 from f5e_rope_table.  Pad rows/columns of q/k/vt are never written: the
  * caller zero-fills them once.
+ * q is stored PRE-SCALED by log2(e) / sqrt(64) (folded in after RoPE, before the bf16 rounding): f5e_flash_attn's scores
+ * are then in the log2 domain with no multiply per element (csrc/attention.hip).
  * q_norm_w / k_norm_w: optional f32[64] RMSNorm weights applied per head before RoPE (qk_norm = "rms_norm", eps 1e-6).
  * Replaces: modules.py:452-461 (projections + head split), :464-467 (qk norm) and :470-480 (apply_rotary_pos_emb). */
 F5E_API int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* q,
@@ -108,6 +110,7 @@ F5E_API int f5e_gemm_bf16_qkv_rope_ln(f5e_stream st, const void* A, int lda, con
 /* ---------------------------------------------------------------- attention ---------------------------------- */
 
 /* o[S*rows_per_seq][ldo] (bf16, column = head*64 + d) = softmax(q k^T / 8 + keymask) v, keys >= kv_len[s] masked.
+ * q as f5e_gemm_bf16_qkv_rope writes it: already multiplied by log2(e) / 8, so the kernel computes 2^(q' k^T - max).
  * q, k, v use the fragment-major layouts documented in csrc/attention.hip; splits: KV splits per 32-query tile
  * (0 = auto, 1, 2 or 4; -1 = the LDS-shared 128-query kernel that auto picks for large problems).
  * Replaces: F.scaled_dot_product_attention + transpose/reshape (modules.py:482-492). */

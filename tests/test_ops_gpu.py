@@ -30,6 +30,9 @@ def dev(t):
     return t.cuda().contiguous()
 
 
+QSCALE = 0.125 * 1.4426950408889634     # log2(e) / sqrt(64): folded into q by the QKV epilogue (f5e_abi.h)
+
+
 def close(a, b, rtol, atol, what=""):
     a, b = a.float().cpu(), b.float().cpu()
     err = (a - b).abs()
@@ -156,7 +159,7 @@ def test_qkv_rope(ops, S, N, H, rope_heads, K, hint):
     ops.gemm_bf16_qkv_rope(dev(a), dev(w), dev(b), q, k, vt, H, rope_heads, cs, N, tile_hint=hint)
     qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)   # fragment-major layouts -> [pos, d]
     unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
-    close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q")
+    close(unq(q, qi)[:, :, :N], q_ref * QSCALE, 2 ** -7, 4e-3 * QSCALE, "q (pre-scaled by log2(e) / 8)")
     close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k")
     close(unq(vt, vi)[:, :, :N], v_ref, 2 ** -7, 4e-3, "v")
     if n_pad > N:   # pad positions are never written
@@ -181,11 +184,12 @@ def pack_qkv(ops, q, k, v, n_pad):
                                                 (2, 2, 33, -1, True), (8, 16, 938, 0, True)])
 def test_flash_attn(ops, S, H, N, waves, masked):
     n_pad = (N + 63) // 64 * 64
-    q = torch.randn(S, H, N, 64, generator=g(12)).to(BF)
+    # q as f5e_gemm_bf16_qkv_rope hands it over: pre-multiplied by log2(e) / 8 before the bf16 rounding (f5e_abi.h)
+    q = (torch.randn(S, H, N, 64, generator=g(12)) * QSCALE).to(BF)
     k = torch.randn(S, H, N, 64, generator=g(13)).to(BF)
     v = torch.randn(S, H, N, 64, generator=g(14)).to(BF)
     lens = torch.tensor([N - 5 * i for i in range(S)], dtype=torch.int32) if masked else None
-    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    s = (q.float() @ k.float().transpose(-1, -2)) * math.log(2.0)           # 2^(q' k) = e^(q k / 8)
     if masked:
         km = torch.arange(N)[None, :] < lens[:, None]
         s = s.masked_fill(~km[:, None, None, :], float("-inf"))
@@ -197,19 +201,29 @@ def test_flash_attn(ops, S, H, N, waves, masked):
     close(out, ref, 2 ** -6, 6e-3, "attention")
 
 
-def test_flash_attn_spike_forces_rescale(ops):
-    """A late key tile with a much larger score forces the online-softmax rescale branch (cdna guide rule 26)."""
-    S, H, N = 1, 1, 256
-    q = torch.randn(S, H, N, 64, generator=g(15)).to(BF)
+@pytest.mark.parametrize("factor", [1.5, 4.0, 12.0])
+def test_flash_attn_spike_forces_rescale(ops, factor):
+    """A late key whose score towers over everything before it (cdna guide rule 26: a rare data-dependent branch needs an
+    input that forces it).  The kernel keeps the maximum of a query's FIRST 64-key step and only checks later row sums:
+    factor 1.5 (~17 octaves above it) stays on the fast path with p ~ 2^17; factor 4 (~46 octaves) trips the row-sum limit
+    and takes the slow path (recompute, true maximum, rescale of l and O); factor 12 (~138 octaves) overflows exp2 to inf
+    first -- the inf must be caught the same way.  Spikes in the first step, in a middle step and in the masked last step."""
+    S, H, N = 1, 1, 300
+    q0 = torch.randn(S, H, N, 64, generator=g(15))
     k = torch.randn(S, H, N, 64, generator=g(16)).to(BF)
     v = torch.randn(S, H, N, 64, generator=g(17)).to(BF)
-    k[0, 0, 200] = (q[0, 0, 17].float() * 4).to(BF)  # score ~ 4*|q|^2/8 >> others, lands in tile 3
-    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    q = (q0 * QSCALE).to(BF)
+    for key, qi in ((200, 17), (40, 99), (290, 250)):
+        k[0, 0, key] = (q0[0, 0, qi] * factor).to(BF)   # score ~ factor |q|^2 / 8 >> the others
+    lens = torch.tensor([295], dtype=torch.int32)
+    s = (q.float() @ k.float().transpose(-1, -2)) * math.log(2.0)
+    s = s.masked_fill(~(torch.arange(N) < 295)[None, None, None, :], float("-inf"))
     ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(S * N, H * 64)
     out = torch.empty(S * N, 64, device="cuda", dtype=BF)
-    for splits in (1, 2, 4):
-        ops.flash_attn(*pack_qkv(ops, q, k, v, N), out, N, waves=splits)
-        close(out, ref, 2 ** -6, 6e-3, f"attention spike, {splits} KV splits")
+    for splits in (1, 2, 4, -1):
+        ops.flash_attn(*pack_qkv(ops, q, k, v, 320), out, N, kv_len=dev(lens), waves=splits)
+        assert torch.isfinite(out.float()).all()
+        close(out, ref, 2 ** -6, 6e-3, f"attention spike x{factor}, {splits} KV splits")
 
 
 @pytest.mark.parametrize("D", [256, 512, 768, 1024])
@@ -534,7 +548,7 @@ def test_qkv_rope_with_qk_rmsnorm(ops, hint):
                            tile_hint=hint)
     qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)
     unq = lambda t, idx: t.cpu().view(S, H, -1)[:, :, idx]
-    close(unq(q, qi)[:, :, :N], q_ref, 2 ** -7, 4e-3, "q normed")
+    close(unq(q, qi)[:, :, :N], q_ref * QSCALE, 2 ** -7, 4e-3 * QSCALE, "q normed (pre-scaled by log2(e) / 8)")
     close(unq(k, qi)[:, :, :N], k_ref, 2 ** -7, 4e-3, "k normed")
     close(unq(vt, vi)[:, :, :N], lin[2], 2 ** -7, 4e-3, "v untouched")
 
