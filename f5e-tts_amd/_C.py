@@ -25,14 +25,13 @@ SIGNATURES = {
     "f5e_gemm_bf16_bias_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "f5e_gemm_bf16_gate_residual_ln": [_P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "f5e_gemm_bf16_qkv_rope_ln": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
-    "f5e_adaln_pre": [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I],
+    "f5e_adaln_pre": [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I],
     "f5e_flash_attn": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I],
     "f5e_layernorm": [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _F],
     "f5e_grn": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_l2norm": [_P, _P, _I, _P, _I, _I, _P, _I, _I],
     "f5e_gemm_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I],
     "f5e_convpos": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I],
-    "f5e_convpos_ln": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I],
     "f5e_dwconv7": [_P, _P, _P, _P, _P, _I, _I, _I],
     "f5e_im2col": [_P, _P, _P, _I, _I, _I, _I, _I],
     "f5e_sinus_embed": [_P, _P, _P, _P, _I, _I, _F],
@@ -77,7 +76,7 @@ class LnFuse(C.Structure):
     """f5e_ln_fuse: one side (consumer: stats..eps, producer: xs_out..stats_out) is filled per launch."""
     _fields_ = [("stats", _P), ("parts", _I), ("c", _P), ("d", _P), ("cd_stride", _I), ("cd_rows", _I),
                 ("cd_eval_stride", _I), ("eval_ptr", _P), ("rows_per_seq", _I), ("eps", _F),
-                ("xs_out", _P), ("ld_xs", _I), ("next_scale", _P), ("stats_out", _P)]
+                ("xs_out", _P), ("ld_xs", _I), ("next_scale", _P), ("stats_out", _P), ("row_mean", _P)]
 
 
 class DitPlan(C.Structure):
@@ -90,11 +89,12 @@ class DitPlan(C.Structure):
         + [("w_skip", _P), ("skip_res", _P), ("skip_tmp", _P)]
         + [(n, _P) for n in ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred")]
         + [("timer", _P), ("timer_op", _I)]
-        + [("fuse_ln", _I), ("ln_stats", _P), ("cd", _P), ("cd_stride", _I)]
+        + [("fuse_ln", _I), ("ln_stats", _P), ("ln_rowmean", _P), ("cd", _P), ("cd_stride", _I)]
         + [("mall_prefetch", _I)]
     )
 
-WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp")
+WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp",
+            "ln_rowmean")
 
 
 class DitWorkspace(C.Structure):

@@ -30,8 +30,6 @@ struct ConvPosArgs {
   const float* resid; int ldr;
   int S, N, D, mode, tiles_t, cpg;
   unsigned long long* trace;  // diagnostics: 8 stamps per workgroup (tools/convpos_time.py)
-  // head of the fused-AdaLN chain (f5e_convpos_ln, split-tap kernel, cpg == 64: one group = one statistics tile)
-  bf16* xs; int ld_xs; const float* scale; const int* eval_ptr; int eval_stride; float* stats; int parts;
 };
 
 __device__ __forceinline__ void glds16c(const void* g, void* lds) {
@@ -248,8 +246,6 @@ __global__ __launch_bounds__(256) void convpos_split_kernel(ConvPosArgs a) {
     }
   }
   const f32x4 bias = *(const f32x4*)(a.bias + n);
-  f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.xs) sc = *(const f32x4*)(a.scale + (a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0) + n);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -342,7 +338,6 @@ __global__ __launch_bounds__(256) void convpos_split_kernel(ConvPosArgs a) {
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int p = 0; p < 4; ++p) asm volatile("" : "+v"(rv[p]));  // see convpos_kernel: one wait here, none between the stores
-  asm volatile("" : "+v"(sc));
 
   if (oc < a.cpg) {
 #pragma unroll
@@ -360,22 +355,6 @@ __global__ __launch_bounds__(256) void convpos_split_kernel(ConvPosArgs a) {
       } else {
         v += rv[p];
         *(f32x4*)(a.out_f32 + m * a.ldo32 + n) = v;
-        if (a.xs) {
-          // f5e_adaln_pre folded in: the 64 channels of this token sit in 16 consecutive lanes = one DPP row
-          const f32x4 y = v * (1.0f + sc);
-          *(bf16x4*)(a.xs + m * a.ld_xs + n) = f2bf4(y[0], y[1], y[2], y[3]);
-          float sm = (v[0] + v[1]) + (v[2] + v[3]);
-          sm = add_xor2(add_xor1(sm));
-          sm += dpp_f32<0x124>(sm);  // row_ror:4
-          sm += dpp_f32<0x128>(sm);  // row_ror:8
-          const float mean = sm * (1.0f / 64.0f);
-          const f32x4 dv = v - mean;
-          float q2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
-          q2 = add_xor2(add_xor1(q2));
-          q2 += dpp_f32<0x124>(q2);
-          q2 += dpp_f32<0x128>(q2);
-          if ((lane & 15) == 0) *(f32x2*)(a.stats + (m * a.parts + g) * 2) = f32x2{mean, q2};
-        }
       }
     }
   }
@@ -450,11 +429,9 @@ extern "C" {
 void f5e_debug_convpos_trace(void* buf) { g_convpos_trace = (unsigned long long*)buf; }
 #endif
 
-// fuse: optional head-of-chain outputs (xs, scale, stats ...) already filled into *fuse; applied only when the
-// split-tap kernel is the one that runs -- *fused says whether it did
 static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
                           void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N,
-                          int D, int groups, const ConvPosArgs* fuse, bool* fused) {
+                          int D, int groups) {
   F5E_REQUIRE(x && w_packed && bias, "convpos: null operand");
   F5E_REQUIRE(S > 0 && N > 0 && D > 0 && groups > 0 && D % groups == 0, "convpos: bad D=%d / groups=%d", D, groups);
   const int cpg = D / groups;
@@ -483,12 +460,6 @@ static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_
 #endif
   const int n_cu = f5e_cu_count();
   const bool split = forced ? forced == 1 : (size_t)groups * a.tiles_t * S <= (size_t)n_cu;
-  if (fused) *fused = false;
-  if (fuse && split && cpg == 64) {
-    a.xs = fuse->xs; a.ld_xs = fuse->ld_xs; a.scale = fuse->scale; a.eval_ptr = fuse->eval_ptr;
-    a.eval_stride = fuse->eval_stride; a.stats = fuse->stats; a.parts = fuse->parts;
-    *fused = true;
-  }
   const int lds_split = xs + 4 * 4 * 8192, lds_ring = xs + 4 * 8192;
   a.trace = F5E_CONVPOS_TRACE;
   static F5eDeviceOnce once_split;
@@ -514,26 +485,7 @@ static int convpos_launch(hipStream_t st, const void* x, int ldx, const void* w_
 int f5e_convpos(hipStream_t st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
                 void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
                 int groups) {
-  return convpos_launch(st, x, ldx, w_packed, bias, mode, out_bf16, ldo, out_f32, ldo32, resid, ldr, S, N, D, groups,
-                        nullptr, nullptr);
-}
-
-int f5e_convpos_ln(hipStream_t st, const void* x, int ldx, const void* w_packed, const float* bias, float* out_f32,
-                   int ldo32, const float* resid, int ldr, int S, int N, int D, int groups, void* xs, int ld_xs,
-                   const float* scale, int mod_stride, int mod_rows, const int* eval_ptr, int eval_stride, float* stats,
-                   int parts) {
-  F5E_REQUIRE(xs && scale && stats && ld_xs % 4 == 0 && parts > 0 && mod_rows > 0, "convpos_ln: bad AdaLN-pre arguments");
-  ConvPosArgs f{};
-  f.xs = (bf16*)xs; f.ld_xs = ld_xs; f.scale = scale; f.eval_ptr = eval_ptr; f.eval_stride = eval_stride;
-  f.stats = stats; f.parts = parts;
-  // the fold needs one statistics tile per group (64 channels) and one modulation row; otherwise two launches
-  const bool can = mod_rows == 1 && parts == groups && groups * 64 == D;
-  bool fused = false;
-  const int rc = convpos_launch(st, x, ldx, w_packed, bias, 1, nullptr, 0, out_f32, ldo32, resid, ldr, S, N, D, groups,
-                                can ? &f : nullptr, &fused);
-  if (rc != F5E_OK || fused) return rc;
-  return f5e_adaln_pre(st, out_f32, ldo32, xs, ld_xs, scale, mod_stride, mod_rows, N, eval_ptr, eval_stride, stats, parts,
-                       S * N, D);
+  return convpos_launch(st, x, ldx, w_packed, bias, mode, out_bf16, ldo, out_f32, ldo32, resid, ldr, S, N, D, groups);
 }
 
 int f5e_dwconv7(hipStream_t st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C) {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   if (EPI == EPI_GATE_RES)
     asm volatile("" ::"s"(a.resid), "s"(a.gate), "s"(a.seq_len), "s"(a.eval_ptr), "s"(a.ldr), "s"(a.gate_stride),
                  "s"(a.gate_rows), "s"(a.eval_stride), "s"(a.bias));
-  if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs));
+  if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs), "s"(a.row_mean));
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
   if (NT == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   f32x2 pf_st[FUSE == 1 ? 4 : 1];
   bool pf_live[PREF ? TM : 1];
   int pf_len[PREF ? TM : 1];
+  float pf_rm[FUSE == 2 ? TM : 1];   // producer: the rows' centring offsets (row means as of the previous norm)
   auto ldv4 = [](const float* ptr) -> f32x4 { return *(const f32x4*)ptr; };
   if (PREF) {
     if (EPI == EPI_GATE_RES) {
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       for (int j = 0; j < TM; ++j) {
         const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
         pf_len[j] = a.seq_len ? a.seq_len[div_magic(mc, a.rows_per_seq, a.rps_magic)] : a.rows_per_seq;
+        if (FUSE == 2) pf_rm[j] = a.row_mean[mc];
       }
     }
   }
@@ -287,8 +289,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       }
     m2 = add_xor2(add_xor1(m2));
     if (sq == 0) {
-      fuse_lds[(tid >> 2) * 2] = mean;
+      fuse_lds[(tid >> 2) * 2] = mean;     // relative to the offset the row's xs was centred with (row_mean)
       fuse_lds[(tid >> 2) * 2 + 1] = rsqrtf(m2 / (float)a.K + a.ln_eps);
+      // the producer behind this consumer centres with the row's CURRENT mean: one workgroup per row tile moves it along
+      if (tile_n == 0 && m0 + (tid >> 2) < a.M) a.row_mean[m0 + (tid >> 2)] += mean;
     }
     __syncthreads();
     if constexpr (DBG == 3) { if (tid == 0) trc[42] = __builtin_amdgcn_s_memtime(); }
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
           if (FUSE == 2) xn[i][j] = x_new;
         }
         if (FUSE == 2) {
-          const f32x4 y = xn[i][j] * (1.0f + pf_ns[i][j]);
+          const f32x4 y = (xn[i][j] - pf_rm[j]) * (1.0f + pf_ns[i][j]);
           *(bf16x4*)(a.xs_out + (size_t)m * a.ld_xs + n) = f2bf4(y[0], y[1], y[2], y[3]);
         }
       } else if (EPI == EPI_GATE_RES) {
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
       q2 = add_xor32(add_xor16(q2));
       if (fq == 0) {
         float* slot = fuse_lds + ((wm0 + j * 16 + fr) * WGN + (wave % WGN)) * 2;
-        slot[0] = mw;
+        slot[0] = mw - pf_rm[j];   // relative to the row's centring offset
         slot[1] = q2;
       }
     }
@@ -548,6 +552,8 @@ int set_consumer(GemmArgs& a, const f5e_ln_fuse* ln, const float* bias) {
   a.ln_stats = ln->stats; a.ln_parts = ln->parts; a.ln_c = ln->c; a.ln_d = ln->d; a.cd_stride = ln->cd_stride;
   a.cd_rows = ln->cd_rows; a.cd_eval_stride = ln->cd_eval_stride; a.ln_eps = ln->eps;
   a.eval_ptr = ln->eval_ptr;
+  F5E_REQUIRE(ln->row_mean, "gemm_bf16: the fused-AdaLN consumer needs f5e_ln_fuse.row_mean (the rows' centring offsets)");
+  a.row_mean = ln->row_mean;
   if (a.rows_per_seq <= 0) a.rows_per_seq = ln->rows_per_seq;
   return F5E_OK;
 }
@@ -588,9 +594,10 @@ int f5e_gemm_bf16_gate_residual_pf(hipStream_t st, const void* A, int lda, const
   F5E_REQUIRE(resid && gate && ldr % 4 == 0 && gate_stride % 4 == 0 && gate_rows > 0 && rows_per_seq > 0,
               "gemm_bf16_gate_residual: bad residual/gate arguments");
   if (ln && ln->stats_out) {
-    F5E_REQUIRE(ln->xs_out && ln->next_scale && ln->ld_xs % 4 == 0 && N % 64 == 0,
-                "gemm_bf16_gate_residual: AdaLN producer needs xs_out, next_scale and N %% 64 == 0");
+    F5E_REQUIRE(ln->xs_out && ln->next_scale && ln->row_mean && ln->ld_xs % 4 == 0 && N % 64 == 0,
+                "gemm_bf16_gate_residual: AdaLN producer needs xs_out, next_scale, row_mean and N %% 64 == 0");
     a.xs_out = (bf16*)ln->xs_out; a.ld_xs = ln->ld_xs; a.next_scale = ln->next_scale; a.stats_out = ln->stats_out;
+    a.row_mean = ln->row_mean;
   }
   return dispatch<EPI_GATE_RES>(a, st, tile_hint);
 }

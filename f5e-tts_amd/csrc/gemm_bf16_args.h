@@ -36,13 +36,18 @@ struct GemmArgs {
   float q_scale;         // factor folded into q after RoPE, before the bf16 rounding: log2(e) / sqrt(64) (attention.hip)
   unsigned long long* trace;  // diagnostics builds only (tools/gemm_trace.hip, tools/pp_timeline.py): per-workgroup timeline
   // Fused AdaLN (FUSE != 0, 64x64 tiles, small M): the LayerNorm+modulate launches between the GEMMs disappear.
-  //   consumer (FUSE 1): A = xs = bf16(x (1 + scale[k])), and with c[n] = sum_k W[n][k] (1 + scale[k]),
-  //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - mean c[n]) + d[n]
+  //   consumer (FUSE 1): A = xs = bf16((x - o) (1 + scale[k])) for a per-row offset o, and with c[n] = sum_k W[n][k] (1 + scale[k]),
+  //     d[n] = sum_k W[n][k] shift[k] + bias[n]:   LN(x)(1+scale)+shift  @ W^T + bias = rstd (acc - (mean - o) c[n]) + d[n]
   //   producer (FUSE 2, gate+residual epilogue): next to x_new it stores xs for the NEXT consumer and, per row and
   //     64-column tile, (mean, M2) of x_new; the consumer combines the tiles with Chan's formula in a fixed order.
   const float* ln_stats; int ln_parts;
   const float* ln_c; const float* ln_d; int cd_stride, cd_rows, cd_eval_stride; float ln_eps;
   bf16* xs_out; int ld_xs; const float* next_scale; float* stats_out;
+  // Centring (round 3): xs = bf16((x - row_mean[m]) (1 + scale)) and the tile means are stored RELATIVE to row_mean[m], the
+  // row's mean as of the previous LayerNorm -- row means drift slowly from norm to norm, so what is rounded to bf16 is of the
+  // size of the row's spread, not of its offset.  The consumer applies  rstd (acc - mean' c[n]) + d[n]  with the relative
+  // mean' it finds in the statistics and (column tile 0 only) moves row_mean[m] += mean' for the producer behind it.
+  float* row_mean;
   int pp_ngroup;   // gemm_bf16_pp.hip: n-tiles per column group of the tile order (0 = plain m-major)
   F5ePrefetch pf;  // weights of the next kernels, pulled into the Infinity Cache by grid-tail workgroups (small M only)
 };

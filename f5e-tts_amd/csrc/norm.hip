@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void layernorm_any_kernel(LnArgs a) {
   }
 }
 
-// Head of the fused-AdaLN chain (see f5e_ln_fuse in the ABI header): no normalisation here, only the row statistics and
-// the pre-scaled bf16 copy the first consumer GEMM runs on.
+// Head of the fused-AdaLN chain (see f5e_ln_fuse in the ABI header): no normalisation here, only the row statistics, the
+// row's centring offset (its exact mean) and the centred, pre-scaled bf16 copy the first consumer GEMM runs on.
 template <int VPL>
 __global__ __launch_bounds__(256) void adaln_pre_kernel(const float* x, int ldx, bf16* xs, int ld_xs, const float* scale,
                                                         int mod_stride, int mod_rows, int rows_per_seq,
                                                         const int* eval_ptr, int eval_stride, float* stats, int parts,
-                                                        int rows, int D) {
+                                                        float* row_mean, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -128,13 +128,15 @@ __global__ __launch_bounds__(256) void adaln_pre_kernel(const float* x, int ldx,
     ss += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
   }
   const float m2 = wave_sum(ss);
+  // statistics are kept RELATIVE to the offset the row's xs was centred with (row_mean): here the exact mean, so 0
   if (lane < parts) {
-    stats[((size_t)row * parts + lane) * 2] = mean;
+    stats[((size_t)row * parts + lane) * 2] = 0.f;
     stats[((size_t)row * parts + lane) * 2 + 1] = m2 / (float)parts;
   }
+  if (lane == 0) row_mean[row] = mean;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const f32x4 y = v[i] * (1.0f + sc[i]);
+    const f32x4 y = (v[i] - mean) * (1.0f + sc[i]);
     *(bf16x4*)(xs + (size_t)row * ld_xs + (i * 64 + lane) * 4) = f2bf4(y[0], y[1], y[2], y[3]);
   }
 }
@@ -289,19 +291,19 @@ int f5e_layernorm(hipStream_t st, const float* x, int ldx, void* y, int ldy, int
 
 int f5e_adaln_pre(hipStream_t st, const float* x, int ldx, void* xs, int ld_xs, const float* scale, int mod_stride,
                   int mod_rows, int rows_per_seq, const int* eval_ptr, int eval_stride, float* stats, int parts,
-                  int rows, int D) {
-  F5E_REQUIRE(x && xs && scale && stats && rows > 0, "adaln_pre: null/empty");
+                  float* row_mean, int rows, int D) {
+  F5E_REQUIRE(x && xs && scale && stats && row_mean && rows > 0, "adaln_pre: null/empty");
   F5E_REQUIRE(D % 256 == 0 && D >= 256 && D <= 2048, "adaln_pre: D=%d must be a multiple of 256 in [256, 2048]", D);
   F5E_REQUIRE(ldx % 4 == 0 && ld_xs % 4 == 0 && mod_stride % 4 == 0, "adaln_pre: strides must be multiples of 4");
   F5E_REQUIRE(parts > 0 && parts <= 32 && mod_rows > 0 && rows_per_seq > 0, "adaln_pre: bad parts / modulation rows");
   const dim3 grid((rows + 3) / 4), block(256);
 #define F5E_PRE_CASE(V)                                                                                               \
   case V: hipLaunchKernelGGL(adaln_pre_kernel<V>, grid, block, 0, st, x, ldx, (bf16*)xs, ld_xs, scale, mod_stride,    \
-                             mod_rows, rows_per_seq, eval_ptr, eval_stride, stats, parts, rows, D); break;
+                             mod_rows, rows_per_seq, eval_ptr, eval_stride, stats, parts, row_mean, rows, D); break;
   switch (D / 256) {
     F5E_PRE_CASE(1) F5E_PRE_CASE(2) F5E_PRE_CASE(3) F5E_PRE_CASE(4) F5E_PRE_CASE(5) F5E_PRE_CASE(6) F5E_PRE_CASE(7)
     default: hipLaunchKernelGGL(adaln_pre_kernel<8>, grid, block, 0, st, x, ldx, (bf16*)xs, ld_xs, scale, mod_stride,
-                                mod_rows, rows_per_seq, eval_ptr, eval_stride, stats, parts, rows, D); break;
+                                mod_rows, rows_per_seq, eval_ptr, eval_stride, stats, parts, row_mean, rows, D); break;
   }
 #undef F5E_PRE_CASE
   F5E_LAUNCH_CHECK("adaln_pre");

@@ -93,6 +93,7 @@ int f5e_workspace_bytes(const f5e_dit_plan* p, f5e_dit_workspace* out) {
   b[F5E_WS_AO] = M * inner * 2;   b[F5E_WS_FF] = M * (unsigned long long)p->FF * 2;
   b[F5E_WS_PRED] = M * (unsigned long long)p->mel * 4;
   b[F5E_WS_LN_STATS] = p->fuse_ln ? M * (D / 64) * 2 * 4 : 0;
+  b[F5E_WS_LN_ROWMEAN] = p->fuse_ln ? M * 4 : 0;
   b[F5E_WS_SKIP_RES] = p->w_skip ? M * D * 4 : 0;
   b[F5E_WS_SKIP_TMP] = p->w_skip ? M * D * 4 : 0;
   unsigned long long off = 0;
@@ -194,10 +195,7 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
                        p->in_const, D, M, nullptr, p->h0, D, p->h0_bf16, D, M, D, p->mel));
   // K5: conv position embedding + residual (dit.py:176)
   F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->h0_bf16, D, p->convpos_w1, p->convpos_b1, 0, p->c1, D, nullptr, 0, nullptr, 0, p->S, p->N, D, p->convpos_groups));
-  // with the fused-AdaLN chain (and no long skip) the second conv also writes the chain's head (xs, statistics)
-  const bool head_in_conv = p->fuse_ln && !p->w_skip;
-  if (!head_in_conv)
-    F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D, p->convpos_groups));
+  F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos(st, p->c1, D, p->convpos_w2, p->convpos_b2, 1, nullptr, 0, p->x, D, p->h0, D, p->S, p->N, D, p->convpos_groups));
 
   if (p->w_skip) {  // long skip connection keeps the embedded input (backbones/dit.py:456-457)
     F5E_REQUIRE(p->skip_res && p->skip_tmp, "dit_forward: long skip needs skip_res / skip_tmp");
@@ -205,20 +203,22 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
             "hipMemcpyAsync(skip_res)");
   }
   if (p->fuse_ln) {
-    // Fused AdaLN chain (f5e_ln_fuse): hn holds xs = bf16(x (1 + scale)) for the next linear, ln_stats the tile
-    // statistics of x; every gate+residual GEMM refreshes both for the norm that follows it.
+    // Fused AdaLN chain (f5e_ln_fuse): hn holds xs = bf16((x - row_mean) (1 + scale)) for the next linear, ln_stats the tile
+    // statistics of x relative to row_mean; every gate+residual GEMM refreshes both for the norm that follows it.
     F5E_REQUIRE(!p->w_skip, "dit_forward: fused AdaLN does not cover the long skip connection");
-    F5E_REQUIRE(p->ln_stats && p->cd && D % 256 == 0 && D <= 1024 && p->mod_rows == 1 && inner == D && p->cd_stride % 4 == 0,
-                "dit_forward: fused AdaLN needs ln_stats, cd tables, D %% 256 == 0, D <= 1024, one modulation row and heads * 64 == D");
+    F5E_REQUIRE(p->ln_stats && p->ln_rowmean && p->cd && D % 256 == 0 && D <= 1024 && p->mod_rows == 1 && inner == D && p->cd_stride % 4 == 0,
+                "dit_forward: fused AdaLN needs ln_stats, ln_rowmean, cd tables, D %% 256 == 0, D <= 1024, one modulation row and heads * 64 == D");
     const int parts = D / 64, ls = 6 * inner + 2 * p->FF, cd_eval_stride = p->mod_rows * p->cd_stride;
     F5E_REQUIRE(p->cd_stride >= p->L * ls + 2 * p->mel, "dit_forward: cd_stride too small");
     f5e_ln_fuse cons{}, prod{};
     cons.stats = p->ln_stats; cons.parts = parts; cons.cd_stride = p->cd_stride; cons.cd_rows = p->mod_rows;
     cons.cd_eval_stride = cd_eval_stride; cons.eval_ptr = p->eval_ptr; cons.rows_per_seq = p->N; cons.eps = 1e-6f;
     prod.xs_out = p->hn; prod.ld_xs = D; prod.stats_out = p->ln_stats;
-    F5E_TIMED(F5E_OP_CONVPOS, f5e_convpos_ln(st, p->c1, D, p->convpos_w2, p->convpos_b2, p->x, D, p->h0, D, p->S, p->N, D,
-                                             p->convpos_groups, p->hn, D, p->mod + D, row_stride, p->mod_rows,
-                                             p->eval_ptr, eval_stride, p->ln_stats, parts));
+    cons.row_mean = prod.row_mean = p->ln_rowmean;
+    // head of the chain: the embedded input's exact row means become the first centring offsets.  (Round 2 folded this
+    // into the second position-embedding conv; a conv workgroup sees 64 of a row's channels, not its mean.)
+    F5E_TIMED(F5E_OP_LN, f5e_adaln_pre(st, p->x, D, p->hn, D, p->mod + D, row_stride, p->mod_rows, p->N, p->eval_ptr, eval_stride,
+                                       p->ln_stats, parts, p->ln_rowmean, M, D));
     // Infinity-Cache prefetch (f5e_common.h): every GEMM / attention launch of a block drags the weights of the launch after
     // next into the memory-side cache with a few grid-tail workgroups, so the batch-1 GEMMs stop waiting for HBM.
     const bool pfon = p->mall_prefetch != 0;

@@ -45,9 +45,10 @@ def _p(t: Optional[Tensor], dtype=None, name="tensor"):
 BF, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 
 
-def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, eval_ptr: Optional[Tensor] = None,
+def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, row_mean: Tensor, eval_ptr: Optional[Tensor] = None,
                 cd_eval_stride: int = 0, eps: float = 1e-6) -> "_C.LnFuse":
-    """Consumer side of the fused AdaLN (see f5e_ln_fuse): stats f32 [M, parts, 2]; c, d f32 [cd_rows, N] views."""
+    """Consumer side of the fused AdaLN (see f5e_ln_fuse): stats f32 [M, parts, 2] (tile means relative to row_mean);
+    c, d f32 [cd_rows, N] views; row_mean f32 [M]: the rows' centring offsets, moved along by this launch."""
     if c.stride(0) != d.stride(0) or c.shape != d.shape:
         raise _C.F5EError("c and d tables must share shape and row stride")
     f = _C.LnFuse()
@@ -55,17 +56,19 @@ def ln_consumer(stats: Tensor, c: Tensor, d: Tensor, rows_per_seq: int, eval_ptr
     f.c, f.d, f.cd_stride, f.cd_rows = c.data_ptr(), d.data_ptr(), c.stride(0), c.shape[0]
     f.cd_eval_stride, f.rows_per_seq, f.eps = cd_eval_stride, rows_per_seq, eps
     f.eval_ptr = eval_ptr.data_ptr() if eval_ptr is not None else None
-    f._keep = (stats, c, d, eval_ptr)
+    f.row_mean = _p(row_mean, F32, "row_mean").value
+    f._keep = (stats, c, d, eval_ptr, row_mean)
     return f
 
 
-def ln_producer(xs_out: Tensor, next_scale: Tensor, stats_out: Tensor) -> "_C.LnFuse":
+def ln_producer(xs_out: Tensor, next_scale: Tensor, stats_out: Tensor, row_mean: Tensor) -> "_C.LnFuse":
     """Producer side: xs_out bf16 [M, N]; next_scale f32 [gate_rows, N] view with the gate's row stride;
-    stats_out f32 [M, N // 64, 2]."""
+    stats_out f32 [M, N // 64, 2]; row_mean f32 [M]: the rows' centring offsets (read)."""
     f = _C.LnFuse()
     f.xs_out, f.ld_xs = _p(xs_out, BF, "xs_out").value, xs_out.stride(0)
     f.next_scale, f.stats_out = next_scale.data_ptr(), _p(stats_out, F32, "stats_out").value
-    f._keep = (xs_out, next_scale, stats_out)
+    f.row_mean = _p(row_mean, F32, "row_mean").value
+    f._keep = (xs_out, next_scale, stats_out, row_mean)
     return f
 
 
@@ -73,15 +76,16 @@ def _ln_ref(ln):
     return C.byref(ln) if ln is not None else None
 
 
-def adaln_pre(x: Tensor, xs: Tensor, scale: Tensor, stats: Tensor, rows_per_seq: int,
+def adaln_pre(x: Tensor, xs: Tensor, scale: Tensor, stats: Tensor, row_mean: Tensor, rows_per_seq: int,
               eval_ptr: Optional[Tensor] = None, eval_stride: int = 0):
-    """Head of the fused-AdaLN chain: xs = bf16(x (1 + scale[r])), stats[row] = `parts` equal shares of (mean, M2)."""
+    """Head of the fused-AdaLN chain: row_mean[row] = mean(x[row]), xs = bf16((x - mean) (1 + scale[r])), stats[row] =
+    `parts` equal shares of (0, M2) (tile means relative to row_mean)."""
     require_device()
     rows, D = x.shape
     check(lib().f5e_adaln_pre(_stream(), _p(x, F32, "x"), x.stride(0), _p(xs, BF, "xs"), xs.stride(0),
                               C.c_void_p(scale.data_ptr()), scale.stride(0), scale.shape[0], rows_per_seq,
                               _p(eval_ptr, I32, "eval_ptr"), eval_stride, _p(stats, F32, "stats"), stats.shape[1],
-                              rows, D), "f5e_adaln_pre")
+                              _p(row_mean, F32, "row_mean"), rows, D), "f5e_adaln_pre")
 
 
 def gemm_bf16_bias(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, act: int = ACT_NONE, tile_hint: int = 0,
@@ -233,20 +237,6 @@ def convpos(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_bf
                             _p(resid, F32, "resid"), resid.stride(0) if resid is not None else 0, S, N, D,
                             w_packed.shape[0]),
           "f5e_convpos")
-
-
-def convpos_ln(x: Tensor, w_packed: Tensor, bias: Tensor, S: int, N: int, *, out_f32: Tensor, resid: Tensor, xs: Tensor,
-               scale: Tensor, stats: Tensor, eval_ptr: Optional[Tensor] = None, eval_stride: int = 0):
-    """Second position-embedding conv + head of the fused-AdaLN chain (``convpos`` mode 1 then ``adaln_pre``), one launch
-    when the grid fits the chip in one round."""
-    require_device()
-    D = x.shape[1]
-    check(lib().f5e_convpos_ln(_stream(), _p(x, BF, "x"), x.stride(0), _p(w_packed, BF, "w_packed"), _p(bias, F32, "bias"),
-                               _p(out_f32, F32, "out_f32"), out_f32.stride(0), _p(resid, F32, "resid"), resid.stride(0),
-                               S, N, D, w_packed.shape[0], _p(xs, BF, "xs"), xs.stride(0),
-                               C.c_void_p(scale.data_ptr()), scale.stride(0), scale.shape[0],
-                               _p(eval_ptr, I32, "eval_ptr"), eval_stride, _p(stats, F32, "stats"), stats.shape[1]),
-          "f5e_convpos_ln")
 
 
 def dwconv7(x: Tensor, w_t: Tensor, bias: Tensor, out: Tensor):

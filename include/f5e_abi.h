@@ -79,12 +79,16 @@ F5E_API int f5e_gemm_bf16_qkv_rope(f5e_stream st, const void* A, int lda, const 
 
 /* Fused AdaLayerNorm for small row counts (batch-1 sampling): the LayerNorm + modulate launch in front of a linear
  * (modules.py:308-314 + :452-454; :637 + :349; :329-335 + dit.py:470) is folded into the GEMMs either side of it.
- *   producer = the gate+residual GEMM before it: next to x_new it writes xs = bf16(x_new (1 + next_scale[n])) and,
- *     per row and 64-column tile, (mean, M2) of x_new into stats_out [M][N / 64][2];
- *   consumer = the linear after it, run on A = xs:  out = rstd (acc - mean c[n]) + d[n]  with the per-evaluation
+ *   producer = the gate+residual GEMM before it: next to x_new it writes xs = bf16((x_new - o) (1 + next_scale[n])) and,
+ *     per row and 64-column tile, (mean - o, M2) of x_new into stats_out [M][N / 64][2], o = row_mean[m];
+ *   consumer = the linear after it, run on A = xs:  out = rstd (acc - mean' c[n]) + d[n]  with the per-evaluation
  *     tables c[n] = sum_k W[n][k] (1 + scale[k]),  d[n] = sum_k W[n][k] shift[k] + bias[n]  (row r =
- *     (m / rows_per_seq) % cd_rows, advanced by (*eval_ptr) * cd_eval_stride), mean / rstd combined from the
- *     `parts` tile statistics (Chan's formula, fixed order); pass bias = NULL to the GEMM.
+ *     (m / rows_per_seq) % cd_rows, advanced by (*eval_ptr) * cd_eval_stride), mean' (relative to o) / rstd combined from
+ *     the `parts` tile statistics (Chan's formula, fixed order); pass bias = NULL to the GEMM.  Its column tile 0 then moves
+ *     row_mean[m] += mean', so the next producer centres with the row's current mean.
+ *   Why centred: bf16(x (1 + scale)) would round at the size of the row's OFFSET, and the error of the normalised result
+ *     would grow like |mean| / std (off-centre rows of trained networks).  Row means drift slowly from norm to norm, so
+ *     with o = the mean as of the previous norm the rounding is at the size of the row's spread, as in the unfused form.
  * Only one side is used per launch; leave the other side's pointers NULL.  Runs on the 64x64 tile family whatever M (the
  * fusion pays at small row counts, where the LayerNorm launches are pure latency; at large M keep f5e_layernorm).
  * Consumer limits: parts a multiple of 4 up to 16 (D <= 1024), cd_rows == 1 (one table row per evaluation). */
@@ -94,6 +98,7 @@ typedef struct f5e_ln_fuse {
   const int* eval_ptr; int rows_per_seq; float eps;
   void* xs_out; int ld_xs; const float* next_scale;    /* producer (next_scale uses the gate's strides / rows) */
   float* stats_out;
+  float* row_mean;                                     /* both sides: [M] f32 centring offsets, see below */
 } f5e_ln_fuse;
 
 F5E_API int f5e_gemm_bf16_bias_ln(f5e_stream st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
@@ -127,11 +132,12 @@ F5E_API int f5e_layernorm(f5e_stream st, const float* x, int ldx, void* y, int l
                   const float* beta, const float* scale, const float* shift, int mod_stride, int mod_rows,
                   int rows_per_seq, const int* eval_ptr, int eval_stride, int rows, int D, float eps);
 
-/* First producer of the fused-AdaLN chain (block 0 has no GEMM in front of its norm): xs = bf16(x (1 + scale[r]))
- * and stats [rows][parts][2] holding `parts` equal shares (mean, M2 / parts) of each row's statistics. */
+/* First producer of the fused-AdaLN chain (block 0 has no GEMM in front of its norm): row_mean[row] = the row's exact
+ * mean, xs = bf16((x - mean) (1 + scale[r])) and stats [rows][parts][2] holding `parts` equal shares (0, M2 / parts) of
+ * each row's statistics (tile means relative to row_mean). */
 F5E_API int f5e_adaln_pre(f5e_stream st, const float* x, int ldx, void* xs, int ld_xs, const float* scale, int mod_stride,
                   int mod_rows, int rows_per_seq, const int* eval_ptr, int eval_stride, float* stats, int parts,
-                  int rows, int D);
+                  float* row_mean, int rows, int D);
 
 /* x_transformers.RMSNorm used by UNetT (backbones/unett.py:151,161,178): y = x / max(||x||_2, 1e-12) * sqrt(D) * g. */
 F5E_API int f5e_l2norm(f5e_stream st, const float* x, int ldx, void* y, int ldy, int y_bf16, const float* g, int rows, int D);
@@ -158,15 +164,6 @@ F5E_API int f5e_gemm_f32(f5e_stream st, const float* A, int lda, int a_rows, int
 F5E_API int f5e_convpos(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, int mode,
                 void* out_bf16, int ldo, float* out_f32, int ldo32, const float* resid, int ldr, int S, int N, int D,
                 int groups);
-
-/* The second conv of ConvPositionEmbedding (mode 1 above) together with the head of the fused-AdaLN chain
- * (f5e_adaln_pre on its output: xs = bf16(out (1 + scale)), statistics per row and 64-column tile).  One launch when the
- * grid fits the chip in one round, D / groups == 64, parts == groups and mod_rows == 1; otherwise f5e_convpos followed
- * by f5e_adaln_pre -- same results up to fp32 summation order.  Arguments as in those two functions. */
-F5E_API int f5e_convpos_ln(f5e_stream st, const void* x, int ldx, const void* w_packed, const float* bias, float* out_f32,
-                   int ldo32, const float* resid, int ldr, int S, int N, int D, int groups, void* xs, int ld_xs,
-                   const float* scale, int mod_stride, int mod_rows, const int* eval_ptr, int eval_stride, float* stats,
-                   int parts);
 
 /* Depthwise Conv1d(C, C, 7, padding 3, groups C), channels-last f32 [B][T][C]; w_t = weight transposed to [7][C]. */
 F5E_API int f5e_dwconv7(f5e_stream st, const float* x, const float* w_t, const float* bias, float* y, int B, int T, int C);
@@ -291,6 +288,7 @@ typedef struct f5e_dit_plan {
   /* fused AdaLN (f5e_ln_fuse): 2 L + 1 LayerNorm launches become one f5e_adaln_pre.  Needs no long skip / qk_norm. */
   int fuse_ln;                           /* 0 = separate LayerNorm launches */
   float* ln_stats;                       /* [S*N][D / 64][2] f32 workspace */
+  float* ln_rowmean;                     /* [S*N] f32 workspace: the rows' centring offsets (f5e_ln_fuse.row_mean) */
   const float* cd;                       /* [E][mod_rows][cd_stride] f32: per block c_qkv | d_qkv | c_ff1 | d_ff1 */
   int cd_stride;                         /*   (3 H 64, 3 H 64, FF, FF), then c_proj | d_proj (mel, mel)          */
   /* batch-1 chains (fused AdaLN path): a few grid-tail workgroups of each block launch pull the weights of the launch after
@@ -305,7 +303,7 @@ typedef struct f5e_dit_plan {
  * need (ln_stats without fuse_ln, skip_* without w_skip) get size 0.  q, k and vt must be zero-filled once by the caller
  * (their pad rows are never written).  Host call, no kernel launch, no allocation. */
 enum { F5E_WS_H0 = 0, F5E_WS_H0_BF16, F5E_WS_C1, F5E_WS_X, F5E_WS_HN, F5E_WS_Q, F5E_WS_K, F5E_WS_VT, F5E_WS_AO, F5E_WS_FF,
-       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_COUNT };
+       F5E_WS_PRED, F5E_WS_LN_STATS, F5E_WS_SKIP_RES, F5E_WS_SKIP_TMP, F5E_WS_LN_ROWMEAN, F5E_WS_COUNT };
 typedef struct f5e_dit_workspace {
   int n_pad;
   unsigned long long bytes[F5E_WS_COUNT];

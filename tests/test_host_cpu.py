@@ -56,7 +56,7 @@ def test_workspace_bytes_planner():
     assert w.n_pad == n_pad
     want = dict(h0=M * 1024 * 4, h0_bf16=M * 1024 * 2, c1=M * 1024 * 2, x=M * 1024 * 4, hn=M * 1024 * 2,
                 q=2 * 16 * n_pad * 64 * 2, k=2 * 16 * n_pad * 64 * 2, vt=2 * 16 * n_pad * 64 * 2, ao=M * 1024 * 2,
-                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0)
+                ff=M * 2048 * 2, pred=M * 100 * 4, ln_stats=0, skip_res=0, skip_tmp=0, ln_rowmean=0)
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got == want
     end = 0
@@ -68,6 +68,7 @@ def test_workspace_bytes_planner():
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == 0
     got = {n: int(w.bytes[i]) for i, n in enumerate(_C.WS_NAMES)}
     assert got["ln_stats"] == M * 16 * 2 * 4 and got["skip_res"] == got["skip_tmp"] == M * 1024 * 4
+    assert got["ln_rowmean"] == M * 4
     p.N = 0
     assert lib.f5e_workspace_bytes(C.byref(p), C.byref(w)) == -1 and b"workspace_bytes" in lib.f5e_last_error()
 
@@ -84,9 +85,9 @@ def test_abi_rejects_bad_shapes_without_launching():
     rc = lib.f5e_flash_attn(None, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1024, None, 1, 16, 100,
                             100, 0)
     assert rc == -1 and b"n_pad" in lib.f5e_last_error()
-    rc = lib.f5e_convpos_ln(None, C.c_void_p(8), 64, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 64, C.c_void_p(8), 64,
-                            1, 8, 64, 1, None, 64, C.c_void_p(8), 64, 1, None, 0, C.c_void_p(8), 1)
-    assert rc == -1 and b"convpos_ln" in lib.f5e_last_error()
+    rc = lib.f5e_adaln_pre(None, C.c_void_p(8), 1024, C.c_void_p(8), 1024, C.c_void_p(8), 1024, 1, 10, None, 0,
+                           C.c_void_p(8), 16, None, 10, 1024)
+    assert rc == -1 and b"adaln_pre" in lib.f5e_last_error()          # no row_mean buffer
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -310,35 +310,6 @@ def test_convpos(ops, S, N, D, G):
     close(o32, F.mish(conv) + res, 1e-4, 2e-4, "mode 1")
 
 
-@pytest.mark.parametrize("S,N,D,G", [(2, 469, 1024, 16), (1, 70, 256, 4), (8, 300, 1024, 16), (2, 100, 768, 16)])
-def test_convpos_ln(ops, S, N, D, G):
-    """Second conv + head of the fused-AdaLN chain: one launch (first two cases) or conv + adaln_pre (ring kernel /
-    narrow groups) -- both must give out, xs = bf16(out (1 + scale)) and statistics that combine to the row mean / var."""
-    cpg, parts, M = D // G, D // 64, S * N
-    x = torch.randn(S, N, D, generator=g(41)).to(BF)
-    w = (torch.randn(D, cpg, 31, generator=g(42)) / math.sqrt(cpg * 31)).to(BF)
-    b = torch.randn(D, generator=g(43)) * 0.1
-    res = torch.randn(M, D, generator=g(44))
-    scale = torch.randn(3, 2 * D, generator=g(45)) * 0.2       # 3 evaluations; the scale row starts at column D
-    ev = torch.tensor([2], dtype=torch.int32)
-    conv = F.conv1d(x.float().permute(0, 2, 1), w.float(), b, padding=15, groups=G).permute(0, 2, 1).reshape(M, D)
-    wp = ops.pack_convpos_weight(w.float(), G)
-    o32 = torch.empty(M, D, device="cuda")
-    xs = torch.empty(M, D, device="cuda", dtype=BF)
-    stats = torch.zeros(M, parts, 2, device="cuda")
-    sc_dev = dev(scale)
-    ops.convpos_ln(dev(x.view(M, D)), dev(wp), dev(b), S, N, out_f32=o32, resid=dev(res), xs=xs,
-                   scale=sc_dev[:1, D:], stats=stats, eval_ptr=dev(ev), eval_stride=2 * D)
-    close(o32, F.mish(conv) + res, 1e-4, 2e-4, "out")
-    out = o32.cpu()
-    close(xs, (out * (1.0 + scale[2, D:])).to(BF).float(), 2 ** -7, 1e-3, "xs")
-    st = stats.cpu().double()
-    mean = st[:, :, 0].mean(1)                                 # equal tile sizes
-    m2 = st[:, :, 1].sum(1) + 64.0 * ((st[:, :, 0] - mean[:, None]) ** 2).sum(1)
-    close(mean.float(), out.mean(1), 1e-5, 1e-5, "mean from statistics")
-    close((m2 / D).float(), out.var(1, unbiased=False), 1e-5, 1e-4, "variance from statistics")
-
-
 def test_dwconv7_im2col(ops):
     B, T, C = 2, 50, 512
     x = torch.randn(B, T, C, generator=g(35))
@@ -447,38 +418,61 @@ def test_istft_head(ops, B, T):
     close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "istft")
 
 
-@pytest.mark.parametrize("ratio", [0.5, 2.0, 8.0])
-def test_fused_adaln_error_grows_with_row_mean_over_std(ops, ratio):
-    """the fused AdaLN rounds xs = bf16(x (1 + scale)) BEFORE the mean is removed, so its error relative to the
-    normalised value scales with |row mean| / std (the separate LayerNorm rounds the normalised value itself).  Documented
-    bound, checked here on rows with |mean| = ratio * std: relative RMS error <= 2^-8 (1 + ratio) of the output spread --
-    i.e. on par with the separate path while |mean| <~ std (what LayerNorm inputs of a trained DiT look like) and degrading
-    linearly beyond; F5E_FUSE_LN=0 selects the separate LayerNorm for a checkpoint whose residual stream is not centred."""
+@pytest.mark.parametrize("ratio", [0.5, 2.0, 8.0, 40.0])
+def test_fused_adaln_is_centred_error_does_not_grow_with_row_mean_over_std(ops, ratio):
+    """the fused AdaLN used to round xs = bf16(x (1 + scale)) BEFORE the mean was removed, so its error
+    grew like |row mean| / std (the separate LayerNorm rounds the normalised value itself) -- unsafe on trained checkpoints
+    with off-centre rows.  Now xs = bf16((x - o)(1 + scale)) with o = the row's mean as of the previous norm
+    (f5e_ln_fuse.row_mean): rows with |mean| = ratio * std, a massive-activation channel on top, head of the chain (o = the
+    exact mean) and a producer -> consumer hop whose update MOVES every row's mean by ~0.3 std (o = the mean before the update).
+    Bound: relative RMS error <= 2^-8 * 2 of the output spread whatever the ratio (was allowed 2^-8 (1 + ratio))."""
     M, D, NO, N = 300, 1024, 1024, 300
     x = torch.randn(M, D, generator=g(90)) + ratio
     x[:, 7] += 40.0                                                         # a massive-activation channel on top
-    mod = torch.randn(1, 2 * D, generator=g(91)) * 0.3
-    scale, shift = mod[:, :D], mod[:, D:]
+    mod = torch.randn(1, 3 * D, generator=g(91)) * 0.3
+    scale, shift, gate = mod[:, :D], mod[:, D:2 * D], mod[:, 2 * D:]
     w = (torch.randn(NO, D, generator=g(92)) / math.sqrt(D)).to(BF)
     b = torch.randn(NO, generator=g(93)) * 0.1
     wf = w.float()
-    ref = (F.layer_norm(x, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
+    cd = (dev(((1 + scale) @ wf.T).contiguous()), dev((shift @ wf.T + b).contiguous()))
     xd, modd = dev(x), dev(mod)
     xs, stats = torch.empty(M, D, device="cuda", dtype=BF), torch.empty(M, D // 64, 2, device="cuda")
-    ops.adaln_pre(xd, xs, modd[:, :D], stats, N)
+    rm = torch.empty(M, device="cuda")
+
+    def errors(x_cpu, x_dev, out):
+        ref = (F.layer_norm(x_cpu, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
+        hn, unf = torch.empty(M, D, device="cuda", dtype=BF), torch.empty(M, NO, device="cuda")
+        ops.layernorm(x_dev, hn, scale=modd[:, :D], shift=modd[:, D:2 * D], rows_per_seq=N)
+        ops.gemm_bf16_bias(hn, dev(w), dev(b), unf)
+        spread = float(ref.std())
+        return (float((out.cpu() - ref).pow(2).mean().sqrt()) / spread, float((unf.cpu() - ref).pow(2).mean().sqrt()) / spread)
+
+    # head of the chain: exact row means
+    ops.adaln_pre(xd, xs, modd[:, :D], stats, rm, N)
+    close(rm, x.mean(1), 1e-5, 1e-5 * (1 + ratio), "row_mean of the head")
     out = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs, dev(w), None, out,
-                       ln=ops.ln_consumer(stats, dev(((1 + scale) @ wf.T).contiguous()), dev((shift @ wf.T + b).contiguous()), N))
-    hn, unf = torch.empty(M, D, device="cuda", dtype=BF), torch.empty(M, NO, device="cuda")
-    ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:], rows_per_seq=N)
-    ops.gemm_bf16_bias(hn, dev(w), dev(b), unf)
-    spread = float(ref.std())
-    e_f = float((out.cpu() - ref).pow(2).mean().sqrt()) / spread
-    e_u = float((unf.cpu() - ref).pow(2).mean().sqrt()) / spread
-    row_std = float(x.std(1).mean())
-    print("mean/std %.2f: fused rms %.2e, separate rms %.2e" % (float(x.mean(1).abs().mean()) / row_std, e_f, e_u))
-    assert e_u < 2 ** -8
-    assert e_f < 2 ** -8 * (1.0 + ratio)
+    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, cd[0], cd[1], N, rm))
+    e_f, e_u = errors(x, xd, out)
+    print("head, mean/std %.1f: fused rms %.2e, separate rms %.2e" % (ratio, e_f, e_u))
+    assert e_u < 2 ** -8 and e_f < 2 ** -8 * 2
+    close(rm, x.mean(1), 1e-5, 1e-5 * (1 + ratio), "row_mean after a consumer with zero drift")
+    # one producer hop: x2 = x + gate * (a2 @ w2^T + b2), an update that shifts every row's mean by about 0.3 std
+    K2 = 2 * D
+    a2 = torch.randn(M, K2, generator=g(94)).to(BF)
+    w2 = (torch.randn(D, K2, generator=g(95)) / math.sqrt(K2)).to(BF)
+    b2 = torch.randn(D, generator=g(96)) * 0.1 + 0.5 * torch.sign(gate.view(-1)) / gate.abs().mean()   # gate * b2 has mean ~ 0.5
+    xs2, st2 = torch.zeros(M, D, device="cuda", dtype=BF), torch.zeros(M, D // 64, 2, device="cuda")
+    x2d = xd.clone()
+    ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2.view(-1)), x2d, modd[:, 2 * D:], N, ln=ops.ln_producer(xs2, modd[:, :D], st2, rm))
+    x2 = x2d.cpu()
+    drift = float((x2.mean(1) - x.mean(1)).abs().mean() / x2.std(1).mean())
+    out2 = torch.empty(M, NO, device="cuda")
+    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, cd[0], cd[1], N, rm))
+    e_f2, e_u2 = errors(x2, x2d, out2)
+    print("hop, mean/std %.1f, drift %.2f std: fused rms %.2e, separate rms %.2e" % (ratio, drift, e_f2, e_u2))
+    assert drift > 0.15
+    assert e_u2 < 2 ** -8 and e_f2 < 2 ** -8 * 2
+    close(rm, x2.mean(1), 1e-4, 1e-5 * (1 + ratio), "row_mean moved along by the consumer")
 
 
 def _stft_fixture():
@@ -577,12 +571,16 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     xd, modd = dev(x), dev(mod)
     xs = torch.empty(M, D, device="cuda", dtype=BF)
     stats = torch.empty(M, P, 2, device="cuda")
-    ops.adaln_pre(xd, xs, modd[:, :D], stats, N)
-    close(xs, (x * (1 + scale)).to(BF), 0, 0, "pre xs")
-    close(stats[:, :, 0], x.mean(1, keepdim=True).expand(M, P), 1e-5, 1e-6, "pre mean")
+    rm = torch.empty(M, device="cuda")
+    ops.adaln_pre(xd, xs, modd[:, :D], stats, rm, N)
+    close(rm, x.mean(1), 1e-5, 1e-6, "pre row mean")
+    close(xs, ((x - rm.cpu()[:, None]) * (1 + scale)).to(BF), 2 ** -7, 1e-6, "pre xs (centred)")   # a bf16 ulp at rounding ties
+    assert float(stats[:, :, 0].abs().max()) == 0                        # tile means relative to the exact mean
     close(stats[:, :, 1].sum(1), ((x - x.mean(1, keepdim=True)) ** 2).sum(1), 1e-5, 1e-4, "pre M2")
     out = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N), tile_hint=hint)
+    ops.gemm_bf16_bias(xs, dev(w), None, out, ln=ops.ln_consumer(stats, dev(c), dev(dd), N, rm), tile_hint=hint)
+    rm0 = rm.cpu().clone()
+    close(rm0, x.mean(1), 1e-5, 1e-6, "row mean unchanged by a consumer without drift")
     hn = torch.empty(M, D, device="cuda", dtype=BF)
     ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:2 * D], rows_per_seq=N)
     unf = torch.empty(M, NO, device="cuda")
@@ -604,17 +602,18 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     xs2 = torch.zeros(M, D, device="cuda", dtype=BF)
     st2 = torch.zeros(M, P, 2, device="cuda")
     ops.gemm_bf16_gate_residual(dev(a2), dev(w2), dev(b2), x_fused, modd[:, 2 * D:], N,
-                                seq_len=dev(seq_len) if masked else None, ln=ops.ln_producer(xs2, modd[:, :D], st2),
+                                seq_len=dev(seq_len) if masked else None, ln=ops.ln_producer(xs2, modd[:, :D], st2, rm),
                                 tile_hint=hint)
     assert torch.equal(x_plain, x_fused)                                    # the residual update itself is unchanged
     xn = x_fused.cpu()
     if masked:
         assert torch.equal(xn[N - 7:N], x[N - 7:N])                         # masked rows keep x ...
-    close(xs2, (xn * (1 + scale)).to(BF), 0, 0, "producer xs")             # ... and still get xs and statistics
+    close(xs2, ((xn - rm0[:, None]) * (1 + scale)).to(BF), 2 ** -7, 1e-6, "producer xs (centred with the previous mean)")
     tiles = xn.view(M, P, 64)
-    close(st2[:, :, 0], tiles.mean(2), 1e-5, 1e-6, "producer tile mean")
+    close(st2[:, :, 0], tiles.mean(2) - rm0[:, None], 1e-5, 2e-6, "producer tile mean (relative)")
     close(st2[:, :, 1], ((tiles - tiles.mean(2, keepdim=True)) ** 2).sum(2), 1e-4, 1e-4, "producer tile M2")
     out2 = torch.empty(M, NO, device="cuda")
-    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N), tile_hint=hint)
+    ops.gemm_bf16_bias(xs2, dev(w), None, out2, ln=ops.ln_consumer(st2, dev(c), dev(dd), N, rm), tile_hint=hint)
+    close(rm, xn.mean(1), 1e-4, 1e-5, "row mean moved along by the consumer")
     ref2 = (F.layer_norm(xn, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
     assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) / float(ref2.std()) < 4e-3
