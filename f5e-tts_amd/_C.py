@@ -53,6 +53,7 @@ SIGNATURES = {
     "f5e_dwconv": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "f5e_softmax_rows": [_P, _P, _I, _P, _I, _P, _LL, _I, _I, _F],
     "f5e_dit_forward": [_P, _P],
+    "f5e_sample_loop": [_P, _P],
     "f5e_workspace_bytes": [_P, _P],
     "f5e_timer_create": [_I, C.POINTER(C.c_void_p)],
     "f5e_timer_destroy": [_P],
@@ -92,6 +93,13 @@ class DitPlan(C.Structure):
         + [("fuse_ln", _I), ("ln_stats", _P), ("ln_rowmean", _P), ("cd", _P), ("cd_stride", _I)]
         + [("mall_prefetch", _I)]
     )
+
+class LoopPlan(C.Structure):
+    """f5e_loop_plan: the fixed-grid ODE loop around one (euler) or two (midpoint) f5e_dit_plan evaluations."""
+    _fields_ = [("eval_a", C.POINTER(DitPlan)), ("eval_b", C.POINTER(DitPlan)), ("steps", _I), ("mode", _I), ("w0", _F),
+                ("w1", _F), ("n", _LL), ("y", _P), ("y_mid", _P), ("pred", _P), ("coef", _P), ("eval_ptr", _P),
+                ("done_ctr", _P), ("traj", _P)]
+
 
 WS_NAMES = ("h0", "h0_bf16", "c1", "x", "hn", "q", "k", "vt", "ao", "ff", "pred", "ln_stats", "skip_res", "skip_tmp",
             "ln_rowmean")

@@ -290,4 +290,31 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
   return F5E_OK;
 }
 
+int f5e_sample_loop(hipStream_t st, const f5e_loop_plan* lp) {
+  F5E_REQUIRE(lp && lp->eval_a, "sample_loop: null plan");
+  F5E_REQUIRE(lp->steps > 0 && lp->n > 0 && lp->y && lp->pred && lp->coef && lp->eval_ptr && lp->done_ctr,
+              "sample_loop: steps, n, y, pred, coef, eval_ptr and done_ctr are required");
+  F5E_REQUIRE(lp->eval_a->eval_ptr == lp->eval_ptr && lp->eval_a->y == lp->y,
+              "sample_loop: eval_a must read the loop's state y and evaluation counter");
+  const bool midpoint = lp->eval_b != nullptr;
+  if (midpoint)
+    F5E_REQUIRE(lp->y_mid && lp->eval_b->y == lp->y_mid && lp->eval_b->eval_ptr == lp->eval_ptr,
+                "sample_loop: eval_b must read y_mid and the loop's evaluation counter");
+  const long long ts = lp->traj ? lp->n : 0;   // trajectory row picked on the device from the evaluation counter
+  for (int i = 0; i < lp->steps; ++i) {
+    F5E_TRY(f5e_dit_forward(st, lp->eval_a));
+    if (!midpoint) {
+      F5E_TRY(f5e_ode_update_traj(st, lp->pred, lp->n, lp->mode, lp->w0, lp->w1, lp->y, lp->y, lp->traj, ts, 1, lp->coef,
+                                  lp->eval_ptr, lp->done_ctr, lp->n));
+    } else {
+      F5E_TRY(f5e_ode_update_traj(st, lp->pred, lp->n, lp->mode, lp->w0, lp->w1, lp->y, lp->y_mid, nullptr, 0, 1, lp->coef,
+                                  lp->eval_ptr, lp->done_ctr, lp->n));
+      F5E_TRY(f5e_dit_forward(st, lp->eval_b));
+      F5E_TRY(f5e_ode_update_traj(st, lp->pred, lp->n, lp->mode, lp->w0, lp->w1, lp->y, lp->y, lp->traj, ts, 2, lp->coef,
+                                  lp->eval_ptr, lp->done_ctr, lp->n));
+    }
+  }
+  return F5E_OK;
+}
+
 }  // extern "C"

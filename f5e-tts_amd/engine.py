@@ -761,12 +761,33 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             forward_all(plans_b)
             ops.ode_update(pred_all, n, inp.mode, inp.w0, inp.w1, y, y, coef_d, eval_ptr, traj_row, done, **kw)
 
+    # One forward over all branches (the default): the step sequence is assembled by the LIBRARY (f5e_sample_loop), so a
+    # reference-side binder needs nothing of this module; the opt-in parallel chains keep the Python-assembled step.
+    loop = None
+    if n_chains == 1:
+        import ctypes as C
+        loop = _C.LoopPlan()
+        loop.eval_a = C.pointer(plans_a[0].c)
+        loop.eval_b = C.pointer(plans_b[0].c) if plans_b else None
+        loop.mode, loop.w0, loop.w1, loop.n = inp.mode, float(inp.w0), float(inp.w1), n
+        loop.y, loop.y_mid = y.data_ptr(), (y_mid.data_ptr() if y_mid is not None else None)
+        loop.pred, loop.coef = pred_all.data_ptr(), coef_d.data_ptr()
+        loop.eval_ptr, loop.done_ctr = eval_ptr.data_ptr(), done.data_ptr()
+        loop.traj = traj.data_ptr() if want_trajectory else None
+
+    def enqueue(reps: int):
+        if loop is not None:
+            loop.steps = reps
+            ops.sample_loop(loop)
+        else:
+            for _ in range(reps):
+                one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
+
     def capture(reps: int) -> ops.Graph:
         gr = ops.Graph()
         gr.begin()
         try:
-            for _ in range(reps):
-                one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
+            enqueue(reps)
         finally:
             gr.end()
         return gr
@@ -785,8 +806,7 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
             for i in range(steps):
                 st.step_graph.launch()
     else:
-        for i in range(steps):
-            one_step(traj[i + 1] if want_trajectory else None)
+        enqueue(steps)
     if not want_trajectory:
         traj[1].copy_(y)
     # the state's buffers are rewritten by this thread's next call: hand back a copy (6 MB at C2, a few us)

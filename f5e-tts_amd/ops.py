@@ -291,6 +291,12 @@ def ode_update(pred: Tensor, branch_stride: int, mode: int, w0: float, w1: float
     return dst
 
 
+def sample_loop(loop: "_C.LoopPlan"):
+    """Enqueue loop.steps ODE steps (network evaluation(s) + guidance combine + Euler / midpoint update) on the current stream."""
+    require_device()
+    check(lib().f5e_sample_loop(_stream(), C.byref(loop)), "f5e_sample_loop")
+
+
 def advance_eval(eval_ptr: Tensor):
     require_device()
     check(lib().f5e_advance_eval(_stream(), _p(eval_ptr, I32, "eval_ptr")), "f5e_advance_eval")

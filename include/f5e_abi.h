@@ -333,6 +333,29 @@ F5E_API void f5e_debug_convpos_trace(void* buf);
 /* One DiT.sample evaluation for S = branches * B sequences (backbones/dit.py:452-470 after the cached embeddings). */
 F5E_API int f5e_dit_forward(f5e_stream st, const f5e_dit_plan* plan);
 
+/* The fixed-grid ODE loop of the samplers (model/cfm.py:430-471 with torchdiffeq's euler / midpoint): enqueues
+ * `steps` steps of   [f5e_dit_forward(eval_a); f5e_ode_update]   (euler) or
+ *                    [f5e_dit_forward(eval_a); update y_mid = y + coef . v; f5e_dit_forward(eval_b); update y = y + coef . v]
+ * (midpoint; eval_b reads y_mid) on `st`.  Nothing is synchronised or allocated: wrap the call in f5e_graph_begin / _end to
+ * get the whole loop as ONE executable graph (what the Python host does), or call it with steps = 1 per step.
+ * Per-step scalars come from device tables indexed by *eval_ptr (the plans' modulation / fused-AdaLN tables, `coef`), which
+ * every update advances by itself through done_ctr -- so one enqueued step serves the whole grid. */
+typedef struct f5e_loop_plan {
+  const f5e_dit_plan* eval_a;  /* the step's (first) evaluation: y = the ODE state, pred = all branches' outputs */
+  const f5e_dit_plan* eval_b;  /* midpoint: second evaluation (y = y_mid); NULL = euler */
+  int steps;                   /* steps to enqueue */
+  int mode; float w0, w1;      /* guidance combine of f5e_ode_update: 0 plain, 1 CFG, 2 three-branch */
+  long long n;                 /* elements of the ODE state: B * N * mel */
+  float* y;                    /* [n] state: y(t_k) in, y(t_k + steps) out */
+  float* y_mid;                /* [n] midpoint scratch (eval_b->y), NULL for euler */
+  const float* pred;           /* [branches][n]: where the evaluations leave their outputs, branch 0 first */
+  const float* coef;           /* [E] step coefficients per evaluation: dt (euler) | dt / 2, dt (midpoint) */
+  int* eval_ptr;               /* device int: evaluation counter (also eval_a / eval_b ->eval_ptr) */
+  unsigned* done_ctr;          /* device u32, zero: arrival counter of the self-advancing update */
+  float* traj;                 /* optional [rows][n]: row (evaluation + 1) / evals_per_step receives y after every step */
+} f5e_loop_plan;
+F5E_API int f5e_sample_loop(f5e_stream st, const f5e_loop_plan* loop);
+
 /* ---------------------------------------------------------------- hipGraph capture --------------------------- */
 F5E_API int f5e_graph_begin(f5e_stream st);
 F5E_API int f5e_graph_end(f5e_stream st, void** graph_exec_out);

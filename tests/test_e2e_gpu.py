@@ -207,6 +207,55 @@ def test_graph_equals_eager_bitwise():
     assert rel_l2(t3[-1], rt3[-1]) < 1.5e-2
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint"])
+def test_sample_loop_c_entry_point_equals_op_by_op_assembly(method, monkeypatch):
+    """f5e_sample_loop (SURVEY 8b's fused loop entry point) enqueues exactly the op sequence a binder would otherwise assemble
+    itself from f5e_dit_forward + f5e_ode_update_traj (reference model/cfm.py:430-471 + torchdiffeq's fixed-grid step): the
+    same sampling call with the loop assembled op by op through the raw C ABI must give the same bits, eagerly and as a graph."""
+    import ctypes as C
+
+    from f5e_tts_amd import _C, ops
+    cfg = O.DiTConfig(**SMALL)
+    sd, dit, cfm = build(cfg)
+    cfm.odeint_kwargs = dict(method=method)
+    wav = SY.synthetic_ref_wave(40).cuda()
+    text = SY.synthetic_text_ids(90, vocab=300)
+    kw = dict(duration=90, steps=5, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+
+    def by_ops(loop):
+        lib, st = _C.lib(), ops._stream()
+        ts = loop.n if loop.traj else 0
+        upd = lambda dst, traj, stride, div: _C.check(lib.f5e_ode_update_traj(   # noqa: E731
+            st, loop.pred, loop.n, loop.mode, loop.w0, loop.w1, loop.y, dst, traj, stride, div, loop.coef, loop.eval_ptr,
+            loop.done_ctr, loop.n), "f5e_ode_update_traj")
+        for _ in range(loop.steps):
+            _C.check(lib.f5e_dit_forward(st, loop.eval_a), "f5e_dit_forward")
+            if not loop.eval_b:
+                upd(loop.y, loop.traj, ts, 1)
+            else:
+                upd(loop.y_mid, None, 0, 1)
+                _C.check(lib.f5e_dit_forward(st, loop.eval_b), "f5e_dit_forward")
+                upd(loop.y, loop.traj, ts, 2)
+
+    res = {}
+    for graph in (False, True):
+        cfm.use_graph = graph
+        for name, fn in (("c", None), ("ops", by_ops)):
+            with monkeypatch.context() as mp:
+                if fn is not None:
+                    mp.setattr(ops, "sample_loop", fn)
+                o1, t1 = cfm.sample(wav, text, **kw)
+                o2, t2 = cfm.sample(wav, text, **kw)       # with graphs: the second call replays the whole-loop graph
+                assert torch.equal(o1, o2) and torch.equal(t1, t2)
+                res[(graph, name)] = (o1.clone(), t1.clone())
+            dit.engine()._loops = __import__("threading").local()    # drop the cached graphs before the other assembly
+    ref = res[(False, "c")]
+    for k, v in res.items():
+        assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k
+    ro, rt = O.cfm_sample(sd, cfg, wav.cpu(), text, None, method=method, **kw)
+    assert rel_l2(ref[1][-1], rt[-1]) < 1.5e-2
+
+
 def test_three_branch_samplers_with_ppg():
     cfg = O.DiTConfig(**dict(SMALL, use_ppg=True, ppg_dim=256, text_mask_padding=False, pe_attn_head=1))
     sd, dit, cfm = build(cfg)
