@@ -285,10 +285,18 @@ class DiTEngine:
 
     def text_embed(self, text: Optional[Tensor], B: int, N: int, drop_text: bool) -> Tensor:
         """TextEmbedding.forward (backbones/dit.py:54-87) -> f32 [B, N, text_dim]."""
+        return self.text_embed_multi(text, B, N, (drop_text,))[0]
+
+    def text_embed_multi(self, text: Optional[Tensor], B: int, N: int, drops: Tuple[bool, ...]) -> List[Tensor]:
+        """TextEmbedding.forward for several drop_text settings of ONE call in one pass: the guidance branches embed the same
+        ids once kept and once dropped (all filler tokens, masked at the same padded positions: dit.py:62-66), so the
+        variants are stacked along the batch axis and every ConvNeXt launch serves all of them (the GRN statistics are per
+        batch item) -> [f32 [B, N, text_dim]] in the order of `drops`."""
         cfg, dv = self.cfg, self.device
+        V = len(drops)
         keep = None
         if text is None:
-            ids = torch.zeros(B, N, dtype=I32, device=dv)
+            ids = torch.zeros(V * B, N, dtype=I32, device=dv)
         else:
             if text.device.type == "cpu" and text[:, :N].numel():
                 # nn.Embedding raises IndexError on an id outside the table (reference backbones/dit.py:59,68: after the
@@ -301,32 +309,30 @@ class DiTEngine:
             ids = (h2d(text, dv) + 1)[:, :N]
             ids = torch.nn.functional.pad(ids, (0, N - ids.shape[1]), value=0)
             if cfg.text_mask_padding:
-                keep = (ids != 0).to(F32).contiguous()  # mask taken BEFORE the drop (dit.py:62-66)
-            if drop_text:
-                ids = torch.zeros_like(ids)
-            ids = ids.to(I32).contiguous()
+                keep = (ids != 0).to(F32).repeat(V, 1).contiguous()  # mask taken BEFORE the drop (dit.py:62-66)
+            ids = torch.cat([torch.zeros_like(ids) if d else ids for d in drops], 0).to(I32).contiguous()
         TD = cfg.text_dim
-        h = torch.empty(B, N, TD, device=dv)
+        VB = V * B
+        h = torch.empty(VB, N, TD, device=dv)
         # reference masks only when there are conv blocks (the masked_fill sits inside `if self.extra_modeling`)
         ops.text_gather(ids, self.text_table, self.text_pos, keep if self.text_blocks else None, h)
-        if not self.text_blocks:
-            return h
-        c = torch.empty_like(h)
-        n = torch.empty_like(h)
-        p1 = torch.empty(B, N, 2 * TD, device=dv)
-        g = torch.empty_like(p1)
-        gws = torch.empty(B, 2 * TD, device=dv)
-        keep_flat = keep.view(-1) if keep is not None else None
-        for blk in self.text_blocks:
-            ops.dwconv7(h, blk["dw_w"], blk["dw_b"], c)
-            ops.layernorm(c.view(B * N, TD), n.view(B * N, TD), gamma=blk["ln_g"], beta=blk["ln_b"])
-            ops.gemm_f32(n.view(B * N, TD), blk["w1"], blk["b1"], out=p1.view(B * N, 2 * TD), act=ops.ACT_GELU_ERF)
-            ops.grn(p1, g, blk["grn_g"], blk["grn_b"], gws)
-            h_new = torch.empty_like(h)
-            ops.gemm_f32(g.view(B * N, 2 * TD), blk["w2"], blk["b2"], out=h_new.view(B * N, TD),
-                         addend=h.view(B * N, TD), row_scale=keep_flat)
-            h = h_new
-        return h
+        if self.text_blocks:
+            c = torch.empty_like(h)
+            n = torch.empty_like(h)
+            p1 = torch.empty(VB, N, 2 * TD, device=dv)
+            g = torch.empty_like(p1)
+            gws = torch.empty(VB, 2 * TD, device=dv)
+            keep_flat = keep.view(-1) if keep is not None else None
+            for blk in self.text_blocks:
+                ops.dwconv7(h, blk["dw_w"], blk["dw_b"], c)
+                ops.layernorm(c.view(VB * N, TD), n.view(VB * N, TD), gamma=blk["ln_g"], beta=blk["ln_b"])
+                ops.gemm_f32(n.view(VB * N, TD), blk["w1"], blk["b1"], out=p1.view(VB * N, 2 * TD), act=ops.ACT_GELU_ERF)
+                ops.grn(p1, g, blk["grn_g"], blk["grn_b"], gws)
+                h_new = torch.empty_like(h)
+                ops.gemm_f32(g.view(VB * N, 2 * TD), blk["w2"], blk["b2"], out=h_new.view(VB * N, TD),
+                             addend=h.view(VB * N, TD), row_scale=keep_flat)
+                h = h_new
+        return [h[v * B:(v + 1) * B] for v in range(V)]
 
     def ppg_embed(self, ppg: Optional[Tensor], B: int, N: int, drop_ppg: bool) -> Tensor:
         """PPGEmbedding.forward (backbones/dit.py:140-153), BatchNorm folded -> f32 [B, N, text_dim]."""
@@ -692,10 +698,11 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
 
     # once-per-call tensors, written into the persistent buffers
     cache: Dict[tuple, Tensor] = {}
+    drops = tuple(sorted({dt_ for _, dt_, _ in inp.branches}))     # every text variant of the call in ONE pass of the ConvNeXt stack
+    for dt_, emb in zip(drops, engine.text_embed_multi(inp.text, B, N, drops)):
+        cache[("t", dt_)] = emb
     for bi, (da, dt_, dp) in enumerate(inp.branches):
         tk = ("t", dt_)
-        if tk not in cache:
-            cache[tk] = engine.text_embed(inp.text, B, N, dt_)
         pe = None
         if cfg.use_ppg:
             pk = ("p", dp)
