@@ -12,6 +12,7 @@ from f5e_tts_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+WAVES = int(os.environ.get("WAVES", "0"))   # KV splits per 32-query tile (0 = auto, -1 = the LDS-shared kernel)
 for S, H, N in ((64, 16, 938), (2, 16, 469)):
     npad = (N + 63) // 64 * 64
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -22,14 +23,14 @@ for S, H, N in ((64, 16, 938), (2, 16, 469)):
         q.zero_(); k.zero_(); v.zero_()
     ao = torch.empty(S * N, H * 64, device="cuda", dtype=BF)
     for _ in range(5):
-        ops.flash_attn(q, k, v, ao, N)
+        ops.flash_attn(q, k, v, ao, N, waves=WAVES)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.flash_attn(q, k, v, ao, N)
+        ops.flash_attn(q, k, v, ao, N, waves=WAVES)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     fl = 4.0 * N * N * 64 * H * S
-    print(f"variant {os.environ.get('F5E_ATTN_VARIANT', '-')}: S={S} H={H} N={N}: {us:.1f} us per launch, {fl / us / 1e6:.0f} TFLOP/s", flush=True)
+    print(f"variant {os.environ.get('F5E_ATTN_VARIANT', '-')} waves {WAVES}: S={S} H={H} N={N}: {us:.1f} us per launch, {fl / us / 1e6:.0f} TFLOP/s", flush=True)

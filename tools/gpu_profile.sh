@@ -5,7 +5,7 @@
 #   workload, digested by tools/pmc_traffic.py.  Summaries -> gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 tag=$1
 R=$(pwd)
-C2="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --steps 5 --warmup 2"
+C2="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --c4-total 0 --steps 5 --warmup 2"
 cd /tmp && export TMPDIR=/tmp
 if [ -z "$SKIP_STATS" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof_c2 -o c2 -- python3 $R/bench.py $C2 > $R/gpurun_out/${tag}_prof_c2.json 2> $R/gpurun_out/${tag}_prof_c2.err || { echo "prof c2 failed"; tail -3 $R/gpurun_out/${tag}_prof_c2.err; exit 1; }
@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_pro
 fi
 # Counter passes launch eagerly (--eager): counter collection crashed (SIGSEGV inside rocprofv3) on the 3700-node whole-loop
 # graph and once hung on replays of the one-step graph; per-kernel counters do not depend on how a kernel was launched.
-PMC="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --steps 2 --warmup 1 --eager"
+PMC="--no-cpu-baseline --no-c3 --no-roofline --streams 0 --c4-total 0 --steps 2 --warmup 1 --eager"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- python3 $R/bench.py $PMC > /dev/null 2> $R/gpurun_out/${tag}_pmc_fetch.err || { echo "pmc fetch failed"; tail -3 $R/gpurun_out/${tag}_pmc_fetch.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o w -- python3 $R/bench.py $PMC > /dev/null 2> $R/gpurun_out/${tag}_pmc_write.err || { echo "pmc write failed"; exit 1; }
 cd $R
