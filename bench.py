@@ -359,11 +359,23 @@ def main():
     if world == 1 and args.streams > 1 and step_frames is None:
         from concurrent.futures import ThreadPoolExecutor
         n_conc = -(-max(args.steps, 8 * args.streams) // args.streams) * args.streams   # a whole number of rounds
+        tls = threading.local()
+
+        def conc_pass(_):
+            # the samplers run on the caller's current stream: a worker that wants to overlap with the others brings its
+            # own (the PyTorch way); inputs were made on the default stream, which is idle by now
+            if not hasattr(tls, "stream"):
+                tls.stream = torch.cuda.Stream()
+            with torch.cuda.stream(tls.stream):
+                out = one_pass()
+                out.record_stream(tls.stream)
+            return out
+
         with ThreadPoolExecutor(max_workers=args.streams) as ex:
-            list(ex.map(lambda _: one_pass(), range(2 * args.streams)))      # per-thread stream / graph warm-up
+            list(ex.map(conc_pass, range(3 * args.streams)))      # per-thread stream / graph warm-up
             torch.cuda.synchronize()
             tc = time.perf_counter()
-            outs = list(ex.map(lambda _: one_pass(), range(n_conc)))
+            outs = list(ex.map(conc_pass, range(n_conc)))
             torch.cuda.synchronize()
             dtc = time.perf_counter() - tc
         same = all(bool(torch.equal(o, last_out)) for o in outs)

@@ -415,6 +415,9 @@ class DiTEngine:
 
     # ------------------------------------------------------------------ plan / workspace
 
+    def plan_fuses(self, M: int, cd: Optional[Tensor]) -> bool:
+        return bool(cd is not None and self.can_fuse_ln and self.fuse_rows_ok(M) and cd.shape[1] == 1)
+
     def plan_shape(self, S: int, B: int, N: int, mod_rows: int, fuse: bool) -> "_C.DitPlan":
         """The shape half of a plan (what f5e_workspace_bytes reads)."""
         cfg = self.cfg
@@ -426,25 +429,38 @@ class DiTEngine:
             p.w_skip = self.skip_w.data_ptr()
         return p
 
-    def workspace(self, p: "_C.DitPlan") -> Tuple["_C.DitWorkspace", Tensor]:
-        """ONE arena sized and laid out by the library (f5e_workspace_bytes); q / k / vt pads zero-filled once."""
+    def workspace_layout(self, p: "_C.DitPlan") -> "_C.DitWorkspace":
         import ctypes as C
         w = _C.DitWorkspace()
         _C.check(_C.lib().f5e_workspace_bytes(C.byref(p), C.byref(w)), "f5e_workspace_bytes")
-        arena = torch.empty(int(w.total), dtype=torch.uint8, device=self.device)
+        return w
+
+    @staticmethod
+    def zero_pads(w: "_C.DitWorkspace", arena: Tensor) -> None:
+        """q / k / vt pad rows are never written by the kernels: the buffers must start out zero."""
         q0 = int(w.offset[_C.WS_NAMES.index("q")])
         q1 = int(w.offset[_C.WS_NAMES.index("vt")] + w.bytes[_C.WS_NAMES.index("vt")])
         arena[q0:q1].zero_()
+
+    def workspace(self, p: "_C.DitPlan", arena: Optional[Tensor] = None) -> Tuple["_C.DitWorkspace", Tensor]:
+        """ONE arena sized and laid out by the library (f5e_workspace_bytes).  Allocated here with its q / k / vt pads
+        zero-filled -- or carved by the caller (run_ode's per-thread pool), who then zeroes the pads when it must."""
+        w = self.workspace_layout(p)
+        if arena is None:
+            arena = torch.empty(int(w.total), dtype=torch.uint8, device=self.device)
+            self.zero_pads(w, arena)
+        elif arena.numel() < int(w.total):
+            raise _C.F5EError(f"workspace arena of {arena.numel()} bytes, {int(w.total)} needed")
         return w, arena
 
     def make_plan(self, S: int, B: int, N: int, y: Tensor, in_const: Tensor, mod: Tensor, eval_ptr: Optional[Tensor],
                   rope_cs: Tensor, seq_len: Optional[Tensor], pred: Optional[Tensor] = None,
-                  cd: Optional[Tensor] = None) -> "_Plan":
+                  cd: Optional[Tensor] = None, arena: Optional[Tensor] = None) -> "_Plan":
         cfg = self.cfg
         M = S * N
-        fuse = bool(cd is not None and self.can_fuse_ln and self.fuse_rows_ok(M) and cd.shape[1] == 1)
+        fuse = self.plan_fuses(M, cd)
         p = self.plan_shape(S, B, N, mod.shape[1], fuse)
-        w, arena = self.workspace(p)
+        w, arena = self.workspace(p, arena)
         assert int(w.n_pad) == p.n_pad
         base = arena.data_ptr()
         for i, name in enumerate(_C.WS_NAMES):
@@ -484,15 +500,17 @@ class _Plan:
 class _LoopState:
     """Everything one (thread, shape) pair needs to integrate again WITHOUT allocating or capturing: the workspace
     arenas, the once-per-call buffers the captured kernels read (in_const, rope table, lengths, counters, ODE state,
-    trajectory) and the instantiated hipGraphs.  The first call with a key captures ONE step and replays it `steps`
-    times (cheap for shapes that never come back, e.g. an eval stream of distinct lengths); from the second call on the
-    WHOLE loop is one graph launch -- no capture, and none of the 8.6 us of idle the GPU spends between two graph
-    launches.  A state belongs to the thread (= side stream) that made it: all writes to its buffers are ordered on
-    that stream, which is what makes the reuse safe without host synchronisation."""
+    trajectory) and the instantiated hipGraphs.  The first call with a key launches eagerly (nothing is captured for
+    shapes that never come back, e.g. an eval stream of distinct lengths), the second captures ONE step and replays it
+    `steps` times, and from the third call on the WHOLE loop is one graph launch -- no capture, and none of the 8.6 us of
+    idle the GPU spends between two graph launches.  A state belongs to the thread (= side stream) that made it: all writes to its buffers are ordered on
+    that stream, which is what makes the reuse safe without host synchronisation.  (Round 3: "that stream" is the caller's
+    current stream -- part of the cache key -- and the side stream only captures.)"""
 
     def __init__(self):
         self.uses = 0
         self.nbytes = 0
+        self.pool: Optional["_Pool"] = None
         self.step_graph: Optional[ops.Graph] = None
         self.loop_graph: Optional[ops.Graph] = None
         self.buf: dict = {}
@@ -503,6 +521,17 @@ class _LoopState:
             if g is not None:
                 g.retire()
         self.step_graph = self.loop_graph = None
+
+
+class _Pool:
+    """Device memory of the persistent loop states of one (thread, stream).  Their runs are ordered on that stream and never
+    overlap in time, so the states of different shapes are all carved from offset 0 of the same buffer: the footprint is
+    the largest shape's, not one arena per cached shape (~1.7 GB per C3-size state, times the LRU depth).
+    `owner` = the state whose run last used the buffer: another state must re-zero its q / k / vt pads."""
+
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.owner = None
 
 
 LOOP_CACHE_ENTRIES = 8   # per thread; a C4-style stream of distinct lengths just cycles through them
@@ -628,9 +657,8 @@ def _publish_state(engine: DiTEngine, key: tuple, st: _LoopState) -> None:
     (engine._loops.pending); CFM._integrate parks them behind an event on the CALLER's stream (retire_pending) -- an event
     recorded on a stream that later captures would be polled by other threads' Graph.reap() during that capture, which
     invalidates it."""
-    st.nbytes = sum(t.numel() * t.element_size() for t in st.buf.values() if isinstance(t, Tensor))
-    for pl in (st.plans_a or []) + (st.plans_b or []):
-        st.nbytes += pl.ws["arena"].numel()
+    # pooled states share one buffer per thread (_Pool): what a cached state costs is its graphs, not device memory
+    st.nbytes = 0 if st.pool is not None else sum(t.numel() * t.element_size() for t in st.buf.values() if isinstance(t, Tensor))
     cache = engine._loops.cache
     cache[key] = st
     pending = getattr(engine._loops, "pending", None)
@@ -650,7 +678,8 @@ def retire_pending(engine: DiTEngine) -> None:
 
 
 def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_trajectory: bool = True,
-            timer: Optional[KernelTimer] = None, chains: Optional[int] = None, setup: Optional[dict] = None) -> Tensor:
+            timer: Optional[KernelTimer] = None, chains: Optional[int] = None, setup: Optional[dict] = None,
+            capture_stream: Optional["torch.cuda.Stream"] = None) -> Tensor:
     """Integrates dy/dt = v(t, y) on the given grid (torchdiffeq fixed-grid euler / midpoint).
 
     Returns the trajectory [steps+1, B, N, mel] (or [2, ...] = (y0, y_final) when want_trajectory is False).
@@ -678,20 +707,51 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     # a stable 60.5 ms for the single batched forward, so the default keeps ONE forward over all branches (weights
     # stream once per step); results are bit-identical either way.
     persistent = use_graph and steps > 1 and timer is None
+    # a state's buffers are written and read in the order of ONE stream: the caller's current stream is part of the key
+    run_stream = torch.cuda.current_stream(dv).cuda_stream
     key = (S, B, N, nb, inp.mode, float(inp.w0), float(inp.w1), inp.method, steps, want_trajectory, n_chains, masked,
-           mod.data_ptr(), cd.data_ptr() if cd is not None else 0, coef_d.data_ptr())
+           mod.data_ptr(), cd.data_ptr() if cd is not None else 0, coef_d.data_ptr(), run_stream)
     st, fresh = _loop_state(engine, key, persistent)
     bf = st.buf
     if fresh:
         bf["keep"] = (mod, cd, coef_d)      # the captured kernels read these: keep them alive past a table-cache eviction
-        bf["in_const"] = torch.empty(S * N, cfg.dim, device=dv)
         bf["rope_cs"] = engine.rope_table(N)
-        bf["seq_len"] = torch.empty(S, dtype=I32, device=dv) if masked else None
-        bf["ctr"] = torch.zeros(2, dtype=I32, device=dv)     # [0] evaluation counter, [1] ode_update's arrival counter
-        bf["traj"] = torch.empty((steps + 1) if want_trajectory else 2, B, N, mel, device=dv)
-        bf["y"] = torch.empty(B, N, mel, device=dv)
-        bf["y_mid"] = torch.empty(B, N, mel, device=dv) if eps_per_step == 2 else None
-        bf["pred_all"] = torch.empty(S * N, mel, device=dv)
+        traj_rows = (steps + 1) if want_trajectory else 2
+        fuse = engine.plan_fuses(per * B * N, cd)
+        ws_bytes = int(engine.workspace_layout(engine.plan_shape(per * B, B, N, mod.shape[1], fuse)).total)
+        n_ws = n_chains * eps_per_step
+        sizes = [("in_const", S * N * cfg.dim * 4), ("seq_len", S * 4 if masked else 0), ("ctr", 8),
+                 ("traj", traj_rows * n * 4), ("y", n * 4), ("y_mid", n * 4 if eps_per_step == 2 else 0),
+                 ("pred_all", S * N * mel * 4)] + [(f"ws{i}", ws_bytes) for i in range(n_ws)]
+        offs, total = {}, 0
+        for name, nb_ in sizes:
+            offs[name] = (total, nb_)
+            total += (nb_ + 255) // 256 * 256
+        if persistent:
+            # every persistent state of this thread lives at offset 0 of ONE pool (see _Pool); a larger shape gets a new
+            # pool, the states built on the old one keep it alive
+            pools = getattr(engine._loops, "pools", None)
+            if pools is None:
+                pools = engine._loops.pools = {}
+            pool = pools.get(run_stream)          # one pool per (thread, stream): its users never overlap in time
+            if pool is None or pool.buf.numel() < total:
+                pool = pools[run_stream] = _Pool(total + total // 4, dv)
+            st.pool, base = pool, pool.buf
+        else:
+            base = torch.empty(total, dtype=torch.uint8, device=dv)
+
+        def carve(name, dtype, *shape):
+            o, nb_ = offs[name]
+            return base[o:o + nb_].view(dtype).view(*shape) if nb_ else None
+
+        bf["in_const"] = carve("in_const", F32, S * N, cfg.dim)
+        bf["seq_len"] = carve("seq_len", I32, S)
+        bf["ctr"] = carve("ctr", I32, 2)     # [0] evaluation counter, [1] ode_update's arrival counter
+        bf["traj"] = carve("traj", F32, traj_rows, B, N, mel)
+        bf["y"] = carve("y", F32, B, N, mel)
+        bf["y_mid"] = carve("y_mid", F32, B, N, mel)
+        bf["pred_all"] = carve("pred_all", F32, S * N, mel)
+        bf["ws"] = [carve(f"ws{i}", torch.uint8, ws_bytes) for i in range(n_ws)]
     in_const, rope_cs, seq_len, traj, y, y_mid, pred_all = (bf[k] for k in ("in_const", "rope_cs", "seq_len", "traj", "y",
                                                                           "y_mid", "pred_all"))
     eval_ptr, done = bf["ctr"][0:1], bf["ctr"][1:2]
@@ -717,17 +777,23 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
     traj[0].copy_(inp.y0)
 
     if fresh:
-        def plans_for(y_in):
+        def plans_for(y_in, first_ws):
             out = []
             for c in range(n_chains):
                 lo, hi = c * per * B * N, (c + 1) * per * B * N
                 sl = seq_len[c * per * B:(c + 1) * per * B] if seq_len is not None else None
                 out.append(engine.make_plan(per * B, B, N, y_in, in_const[lo:hi], mod, eval_ptr, rope_cs, sl,
-                                            pred=pred_all[lo:hi], cd=cd))
+                                            pred=pred_all[lo:hi], cd=cd, arena=bf["ws"][first_ws + c]))
             return out
 
-        st.plans_a = plans_for(y)
-        st.plans_b = plans_for(y_mid) if y_mid is not None else None
+        st.plans_a = plans_for(y, 0)
+        st.plans_b = plans_for(y_mid, n_chains) if y_mid is not None else None
+    if st.pool is None or st.pool.owner is not st:
+        # the buffer was last used by a state of another shape (or never): the q / k / vt pad rows must read as zeros
+        for pl in st.plans_a + (st.plans_b or []):
+            engine.zero_pads(pl.layout, pl.ws["arena"])
+        if st.pool is not None:
+            st.pool.owner = st
     plans_a, plans_b = st.plans_a, st.plans_b
     if timer is not None:
         if use_graph:
@@ -791,25 +857,35 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
                 one_step(traj if want_trajectory else None, whole_traj=want_trajectory)
 
     def capture(reps: int) -> ops.Graph:
+        # Capture needs a non-default stream; it executes nothing, so it needs no ordering against the caller's stream
+        # either.  Everything that RUNS -- the once-per-call kernels above, eager steps, graph launches -- stays on the
+        # caller's current stream: no cross-queue hand-off per call (measured at C2 / C4 below).
+        import contextlib
         gr = ops.Graph()
-        gr.begin()
-        try:
-            enqueue(reps)
-        finally:
-            gr.end()
+        with (torch.cuda.stream(capture_stream) if capture_stream is not None else contextlib.nullcontext()):
+            gr.begin()
+            try:
+                enqueue(reps)
+            finally:
+                gr.end()
         return gr
 
     if persistent:
+        # A shape's FIRST call runs eagerly: capturing + instantiating even one step costs ~1.2 ms (C4 stream of distinct
+        # lengths: 39.3 ms per utterance with a capture per shape, 38.1 without), and the eager launches of one C call per
+        # evaluation are not host-bound.  The second call captures ONE step and replays it; from the third call on the
+        # whole loop is one graph launch.  All three forms give the same bits.
         st.uses += 1
-        if st.loop_graph is None and st.uses >= 2 and LOOP_GRAPH:
-            st.loop_graph = capture(steps)         # this shape came back: from now on one launch per call
+        if st.loop_graph is None and st.uses >= 3 and LOOP_GRAPH:
+            st.loop_graph = capture(steps)         # this shape keeps coming back: from now on one launch per call
         if st.loop_graph is not None:
             st.loop_graph.launch()
+        elif st.uses == 1:
+            _publish_state(engine, key, st)        # buffers and plans exist: the state may be reused
+            enqueue(steps)
         else:
             if st.step_graph is None:
                 st.step_graph = capture(1)
-            if fresh:
-                _publish_state(engine, key, st)    # buffers, plans and the first capture exist: now it may be reused
             for i in range(steps):
                 st.step_graph.launch()
     else:

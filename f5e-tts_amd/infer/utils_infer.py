@@ -317,7 +317,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     # loop (`next(result)`, :514-518).  Default here = the same order on the calling thread, so with seed=None the noise
     # of chunk i is the i-th draw from the global CPU generator exactly as in the reference (reproducible under
     # torch.manual_seed); the GPU still overlaps chunks with the host because nothing above waits for it.
-    # F5E_INFER_WORKERS=k (2..4) opts into k host threads, each with its own capture stream (the engine keeps
+    # F5E_INFER_WORKERS=k (2..4) opts into k host threads, each on its own stream (the engine keeps
     # per-call buffers private per thread): more throughput on one GPU, and a per-chunk seed drawn in submission order on
     # this thread keeps the result independent of thread timing (a different noise stream than the serial default).
     workers = max(1, min(4, int(os.environ.get("F5E_INFER_WORKERS", "1"))))
@@ -325,8 +325,20 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
         results = [to_host(r) for r in [process_batch(g) for g in gen_text_batches]]
     else:
         seeds = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) for _ in gen_text_batches]
+        import threading
+        tls = threading.local()
+        main_stream = torch.cuda.current_stream()
+
+        def on_own_stream(a):
+            # the samplers run on the caller's current stream: every worker brings its own, ordered behind this thread's
+            if not hasattr(tls, "stream"):
+                tls.stream = torch.cuda.Stream()
+                tls.stream.wait_stream(main_stream)
+            with torch.cuda.stream(tls.stream):
+                return to_host(process_batch(*a))
+
         with ThreadPoolExecutor(max_workers=workers) as ex:
-            results = list(ex.map(lambda a: to_host(process_batch(*a)), zip(gen_text_batches, seeds)))
+            results = list(ex.map(on_own_stream, zip(gen_text_batches, seeds)))
     waves = [r[0] for r in results]
     specs = [r[1] for r in results]
     if waves:

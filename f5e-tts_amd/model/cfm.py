@@ -143,18 +143,15 @@ class CFM(nn.Module):
                             seq_len=prep["seq_len"], branches=branches, mode=mode, w0=w0, w1=w1,
                             method=self.odeint_kwargs.get("method", "euler"))
         if self.use_graph:
-            # graph capture needs a non-default stream; order it after the caller's stream and hand back afterwards
-            cur = torch.cuda.current_stream(eng.device)
+            # graph CAPTURE needs a non-default stream (one per thread); what runs -- eager steps, graph launches, the
+            # once-per-call kernels -- stays on the caller's current stream, as every other op of this package does
             side = getattr(self._tls, "stream", None)
             if side is None:
                 side = self._tls.stream = torch.cuda.Stream(device=eng.device)
             setup = ode_setup(eng, inp)   # pinned uploads + shared tables on the caller's stream, see ode_setup
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup)
-            cur.wait_stream(side)
-            # graphs of loop states evicted by this call: parked behind an event on the CALLER's stream (which now covers
-            # every launch of the side stream), never on the stream that captures (engine._publish_state)
+            trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup, capture_stream=side)
+            # graphs of loop states evicted by this call: parked behind an event on the CALLER's stream, never on the
+            # stream that captures (engine._publish_state)
             retire_pending(eng)
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)

@@ -67,9 +67,10 @@ def test_c2_full_nfe32_graph_and_vocos_vs_oracle():
     wav, text = SY.synthetic_ref_wave(n_ref), SY.synthetic_text_ids(n)
     kw = dict(duration=n, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
     ref_out, ref_traj = O.cfm_sample(sd, cfg, wav, text, None, **kw)
-    out, traj = cfm.sample(wav.cuda(), text, **kw)          # first call: one-step graph replayed 32 times
-    out2, traj2 = cfm.sample(wav.cuda(), text, **kw)        # second call, same shape: the whole loop as ONE graph launch
-    assert torch.equal(out, out2) and torch.equal(traj, traj2)
+    out, traj = cfm.sample(wav.cuda(), text, **kw)          # first call of a shape: eager launches
+    out2, traj2 = cfm.sample(wav.cuda(), text, **kw)        # second call: one-step graph replayed 32 times
+    out3, traj3 = cfm.sample(wav.cuda(), text, **kw)        # third call: the whole loop as ONE graph launch
+    assert torch.equal(out, out2) and torch.equal(traj, traj2) and torch.equal(out, out3) and torch.equal(traj, traj3)
     assert out.shape == ref_out.shape == (1, n, 100) and traj.shape == ref_traj.shape == (33, 1, n, 100)
     assert torch.equal(traj[0].cpu(), ref_traj[0])          # seeded CPU noise is bit-identical
     torch.testing.assert_close(out[:, :n_ref].cpu(), ref_out[:, :n_ref], rtol=1e-4, atol=2e-4)   # stitched reference mel

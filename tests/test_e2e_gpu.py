@@ -196,8 +196,9 @@ def test_graph_equals_eager_bitwise():
     cfm.use_graph = False
     o1, t1 = cfm.sample(cond.cuda(), text.cuda(), **kw)
     cfm.use_graph = True
-    o2, t2 = cfm.sample(cond.cuda(), text.cuda(), **kw)
-    assert torch.equal(o1, o2) and torch.equal(t1, t2)
+    for form in ("first call of the shape: eager on the capture stream", "one-step graph replayed", "whole-loop graph"):
+        o2, t2 = cfm.sample(cond.cuda(), text.cuda(), **kw)
+        assert torch.equal(o1, o2) and torch.equal(t1, t2), form
     ref_out, ref_traj = O.cfm_sample(sd, cfg, cond, text, None, **kw)
     assert rel_l2(t2[-1], ref_traj[-1]) < 1.5e-2
     # midpoint solver and the no-CFG single-branch path
@@ -244,9 +245,10 @@ def test_sample_loop_c_entry_point_equals_op_by_op_assembly(method, monkeypatch)
             with monkeypatch.context() as mp:
                 if fn is not None:
                     mp.setattr(ops, "sample_loop", fn)
-                o1, t1 = cfm.sample(wav, text, **kw)
-                o2, t2 = cfm.sample(wav, text, **kw)       # with graphs: the second call replays the whole-loop graph
-                assert torch.equal(o1, o2) and torch.equal(t1, t2)
+                o1, t1 = cfm.sample(wav, text, **kw)       # with graphs: eager launches, ...
+                o2, t2 = cfm.sample(wav, text, **kw)       # ... the one-step graph replayed, ...
+                o3, t3 = cfm.sample(wav, text, **kw)       # ... the whole-loop graph
+                assert torch.equal(o1, o2) and torch.equal(t1, t2) and torch.equal(o1, o3) and torch.equal(t1, t3)
                 res[(graph, name)] = (o1.clone(), t1.clone())
             dit.engine()._loops = __import__("threading").local()    # drop the cached graphs before the other assembly
     ref = res[(False, "c")]
