@@ -365,8 +365,9 @@ __global__ __launch_bounds__(NSPLIT * 64, 2) void attn_fwd_kernel(AttnArgs a) { 
 // every 64-key K/V tile is fetched ONCE per workgroup into LDS (3-stage LDS-DMA ring, counted vmcnt + raw barrier,
 // as in gemm_bf16.hip) instead of once per wave from L2: 4x less L2->CU traffic, which is what bounds the LDS-free
 // kernel once S*H*N^2 is large (C3: 7.4 GB of L2 reads per call).  The fragment-major K / V tiles are contiguous in
-// memory (K: 2 x 4 KiB, V: 2 x 4 KiB per 64 keys), so the DMA is a linear copy and a fragment read is
-// ds_read_b128 at fragment*1 KiB + (lane&31)*32 + (lane>>5)*16 (2-way bank conflict, LDS is far from saturated).
+// memory (K: 2 x 4 KiB, V: 2 x 4 KiB per 64 keys), so the DMA copies 1 KiB fragments (lanes permuted, see `stage`) and a
+// fragment read is ds_read_b128 at fragment*1 KiB + lane*16 (conflict-free; round 2 read the memory order, 2-way conflicts:
+// SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE, profiles/r03_d_pmc_attention_c3_b.json).
 // NST = ring depth (48 / 32 KiB of LDS -> 3 / 5 workgroups per CU by LDS), OCC = waves per SIMD the register allocation must
 // leave room for (__launch_bounds__ second argument: 4 -> <= 128 VGPRs, 5 -> <= 96).  Shipped: <2, 4> (C3, us per launch: 3
 // stages -> 3 workgroups per CU 324; 2 stages -> 4 per CU, VGPR-limited, 292; forcing 5 per CU with 3 spills 300; row sums
@@ -407,14 +408,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + ((size_t)(qt * 4 + ks) * 32 + ql) * 16 + hh * 8);
 
   // stage t64: K bytes [t64*8192, +8192) and V bytes [t64*8192, +8192); 1024 chunks of 16 B, 4 per thread
+  // LDS image of a fragment: lane l's 16 bytes at byte 16 l (conflict-free ds_read_b128: the four 16-lane groups of the
+  // instruction each cover all 64 banks), i.e. LDS chunk i holds memory chunk 2 (i & 31) + (i >> 5) of the fragment -- the
+  // DMA permutes on the SOURCE side (its LDS side is fixed at base + 16 lane); a wave still reads 1 KiB contiguous.
+  const int src16 = ((lane & 31) * 2 + (lane >> 5)) * 16;
   auto stage = [&](int buf, int t64) {
     char* dst = smem + buf * TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int off = (wave * 64 + 256 * j) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + (size_t)t64 * 8192 + off + lane * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kg + (size_t)t64 * 8192 + off + src16),
                                        (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (size_t)t64 * 8192 + off + lane * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vg + (size_t)t64 * 8192 + off + src16),
                                        (__attribute__((address_space(3))) void*)(dst + 8192 + off), 16, 0, 0);
     }
   };
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x8 kf = *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16);
+          const bf16x8 kf = *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + lane * 16);
           d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? c : d[t], 0, 0, 0);
         }
     };
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[t][8 * s + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + ql * 32 + hh * 16);
+          const bf16x8 vf = *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + lane * 16);
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
         }
       }
@@ -488,8 +493,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   for (int t64 = 1; t64 < nfull; ++t64) {
     const char* Ks = tile_begin(t64);
     const char* Vs = Ks + 8192;
-    auto kfrag = [&](int t, int ks) { return *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + ql * 32 + hh * 16); };
-    auto vfrag = [&](int t, int s, int dt) { return *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + ql * 32 + hh * 16); };
+    auto kfrag = [&](int t, int ks) { return *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + lane * 16); };
+    auto vfrag = [&](int t, int s, int dt) { return *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + lane * 16); };
     fast_step(kfrag, vfrag, qf, minit, l_val, oacc);
   }
   if (nfull < ntiles && ntiles > 1) checked_tile(ntiles - 1);

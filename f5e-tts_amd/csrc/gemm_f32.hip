@@ -295,9 +295,13 @@ template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 int launch_dma(Gemm32Args& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   const int grid = a.tiles_m * ((a.N + BN - 1) / BN);
-  constexpr int lds = NSTAGE * (BM + BN) * 256;
+  constexpr int lds_max = NSTAGE * (BM + BN) * 256;
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), lds);
+  if (lds_max > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), lds_max);
+  // a K of fewer tiles than ring slots never re-stages: slots >= KT are untouched, so they need not exist.  The per-step
+  // input projection (K = 100: 2 tiles) then takes 64 instead of 96 KiB and two workgroups share a CU.
+  const int kt = (a.K + 63) / 64;
+  const int lds = (kt < NSTAGE ? kt : NSTAGE) * (BM + BN) * 256;
   hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, WGM, WGN, NSTAGE>), dim3(grid), dim3(256), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_f32_dma");
   return F5E_OK;
