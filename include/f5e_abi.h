@@ -325,7 +325,7 @@ F5E_API int f5e_timer_read_ops(void* timer, int* ops_out_host, int max_out, int*
 
 #ifdef F5E_TOOLS
 /* Diagnostics, TOOLS build only (make -C f5e-tts_amd/csrc tools-lib -> libf5e_hip_tools.so; tools/convpos_time.py): while
- * buf != NULL, f5e_convpos / f5e_convpos_ln launch a build of their kernels that writes 8 timestamps per workgroup.  This is
+ * buf != NULL, f5e_convpos launches a build of its kernels that writes 8 timestamps per workgroup.  This is
  * process-wide mutable state, which is why the shipped libf5e_hip.so neither contains nor exports it. */
 F5E_API void f5e_debug_convpos_trace(void* buf);
 #endif
