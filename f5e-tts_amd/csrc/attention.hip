@@ -47,7 +47,7 @@ struct AttnArgs {
   bf16* o; int ldo;
   const int* kv_len;  // [S] or null (= rows_per_seq)
   int S, H, rows_per_seq, n_pad;
-  int n_main;         // workgroups beyond it only prefetch (NSPLIT == 4 launches: 256 threads)
+  int n_main;         // workgroups beyond it only prefetch (NSPLIT >= 2 launches)
   F5ePrefetch pf;
 };
 
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(NSPLIT * 64, 2) void attn_fwd_kernel(AttnArgs a) { 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
-  if (NSPLIT == 4 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
-    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, threadIdx.x, red);
+  if constexpr (NSPLIT >= 2) if ((int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+    f5e_prefetch_run<NSPLIT * 64>(a.pf, (int)blockIdx.x - a.n_main, threadIdx.x, red);
     return;
   }
 
@@ -562,7 +562,12 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
   }
   switch (splits) {
     case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid), dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid), dim3(128), 0, st, a); break;
+    case 2: {
+      const int npf = f5e_prefetch_wgs(pf);
+      if (npf) a.pf = *pf;
+      hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(grid + npf), dim3(128), 0, st, a);
+      break;
+    }
     case 4: {
       const int npf = f5e_prefetch_wgs(pf);
       if (npf) a.pf = *pf;

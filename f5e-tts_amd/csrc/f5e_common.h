@@ -83,15 +83,16 @@ inline int f5e_prefetch_wgs(const F5ePrefetch* pf) {
   unsigned long long b = (pf->ptr[0] ? pf->bytes[0] : 0) + (unsigned long long)(pf->ptr[1] ? pf->bytes[1] : 0);
   return (int)((b + F5E_PF_BYTES_PER_WG - 1) / F5E_PF_BYTES_PER_WG);
 }
-// workgroup `wg` (0-based among the prefetch workgroups) of a 256-thread launch.  The loads are LDS-DMAs into 4 KiB of
+// workgroup `wg` (0-based among the prefetch workgroups) of an NT-thread launch.  The loads are LDS-DMAs into 4 KiB of
 // the workgroup's (otherwise unused) LDS: no destination VGPR, so no register of this wave can be overwritten by a load
 // that lands late, and nothing ever reads what arrives.
+template <int NT = 256>   // threads of the hosting launch (256, or 128 for the 2-way split attention kernel)
 __device__ __forceinline__ void f5e_prefetch_run(const F5ePrefetch& pf, int wg, int tid, void* lds) {
   unsigned long long off = (unsigned long long)wg * F5E_PF_BYTES_PER_WG + (unsigned)tid * 16u;
   const unsigned long long b0 = pf.ptr[0] ? pf.bytes[0] : 0, b1 = pf.ptr[1] ? pf.bytes[1] : 0;
   char* dst = (char*)lds + (tid >> 6) * 1024;   // wave-uniform base; the DMA adds lane * 16
 #pragma unroll
-  for (int i = 0; i < F5E_PF_BYTES_PER_WG / (256 * 16); ++i, off += 256 * 16) {
+  for (int i = 0; i < F5E_PF_BYTES_PER_WG / (NT * 16); ++i, off += NT * 16) {
     const char* p = nullptr;
     if (off + 16 <= b0) p = (const char*)pf.ptr[0] + off;
     else if (off >= b0 && off - b0 + 16 <= b1) p = (const char*)pf.ptr[1] + (off - b0);
