@@ -430,16 +430,25 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   // Ring bookkeeping of one 64-key step: wait until tile t64 has landed (NST - 2 younger tiles of 4 DMAs each may stay in
   // flight) and every wave is done reading tile t64 - 1, stage tile t64 + NST - 1, return the slot of tile t64.
   int buf = 0, nbuf = NST - 1;
-  auto tile_begin = [&](int t64) -> const char* {
+  // tile_wait: tile t64 has landed and every wave is done with tile t64 - 1; tile_stage: fetch tile t64 + NST - 1 into the
+  // slot that freed.  The fast loop issues its first K-fragment reads BETWEEN the two: a DMA instruction costs the wave
+  // 100+ cycles of issue while the CU's address path is busy, and reads issued behind it wait that long (gemm_bf16.hip).
+  auto tile_wait = [&](int t64) -> const char* {
     const int young = min(NST - 2, ntiles - 1 - t64);   // tiles staged after t64 that may stay in flight
     if (young >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if (young == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    return smem + buf * TILE_BYTES;
+  };
+  auto tile_stage = [&](int t64) {
     if (t64 + NST - 1 < ntiles) stage(nbuf, t64 + NST - 1);
-    const char* Ks = smem + buf * TILE_BYTES;
     buf = (buf == NST - 1) ? 0 : buf + 1;
     nbuf = (nbuf == NST - 1) ? 0 : nbuf + 1;
+  };
+  auto tile_begin = [&](int t64) -> const char* {
+    const char* Ks = tile_wait(t64);
+    tile_stage(t64);
     return Ks;
   };
   auto pass_begin = [&]() {
@@ -491,9 +500,13 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_lds_kernel(AttnArgs a) {
   if (ntiles > 0) checked_tile(0);
   const int nfull = (ntiles > 0 && ntiles * 64 > kv_len) ? ntiles - 1 : ntiles;   // steps without a key mask
   for (int t64 = 1; t64 < nfull; ++t64) {
-    const char* Ks = tile_begin(t64);
+    const char* Ks = tile_wait(t64);
     const char* Vs = Ks + 8192;
-    auto kfrag = [&](int t, int ks) { return *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + lane * 16); };
+    bf16x8 kf0[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf0[ks] = *(const bf16x8*)(Ks + ks * 1024 + lane * 16);
+    tile_stage(t64);
+    auto kfrag = [&](int t, int ks) { return t == 0 ? kf0[ks] : *(const bf16x8*)(Ks + (t * 4 + ks) * 1024 + lane * 16); };
     auto vfrag = [&](int t, int s, int dt) { return *(const bf16x8*)(Vs + (((t * 2 + s) * 2 + dt) * 1024) + lane * 16); };
     fast_step(kfrag, vfrag, qf, minit, l_val, oacc);
   }

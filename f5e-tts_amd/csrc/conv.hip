@@ -144,28 +144,31 @@ __global__ __launch_bounds__(256) void convpos_kernel(ConvPosArgs a) {
     wait_vm_lgkm0(2 * (issued - tap - 1));
     __builtin_amdgcn_s_barrier();
     if constexpr (TRC) { if (tap == 0) ts[2] = __builtin_amdgcn_s_memtime(); if (tap == 10) ts[3] = __builtin_amdgcn_s_memtime(); if (tap == 20) ts[4] = __builtin_amdgcn_s_memtime(); }
-    if (tap + NST - 1 < TAPS) stage_w((tap + NST - 1) % NST, tap + NST - 1);
     const char* Ws = Wsb + (tap % NST) * W_BYTES;
+    // fragment reads first, the next tap's weight DMAs behind them, then the MFMAs (K-step order: gemm_bf16.hip)
+    bf16x8 xf[2][2], wf[2][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int c = kk * 4 + fq;
-      bf16x8 xf[2], wf[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = wm0 + j * 16 + fr + tap;
-        xf[j] = *(const bf16x8*)(Xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        xf[kk][j] = *(const bf16x8*)(Xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = wn0 + i * 16 + fr;
-        wf[i] = *(const bf16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        wf[kk][i] = *(const bf16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
+    }
+    if (tap + NST - 1 < TAPS) stage_w((tap + NST - 1) % NST, tap + NST - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
   }
 
   if constexpr (TRC) ts[5] = __builtin_amdgcn_s_memtime();
@@ -298,15 +301,13 @@ __global__ __launch_bounds__(256) void convpos_split_kernel(ConvPosArgs a) {
       __builtin_amdgcn_s_barrier();  // the activation tile is staged by all four waves
       if constexpr (TRC) ts[2] = __builtin_amdgcn_s_memtime();
     }
-    if (u + NST - 1 < 8) stage_w((u + NST - 1) % NST, u + NST - 1);
     if constexpr (TRC) { if (u == 1) ts[3] = __builtin_amdgcn_s_memtime(); if (u == 4) ts[4] = __builtin_amdgcn_s_memtime(); }
     const int tap = wave + 4 * u;
-    if (u == 7 && tap >= TAPS) break;
+    const bool live = !(u == 7 && tap >= TAPS);      // wave-uniform: the last round has taps for waves 0-2 only
     const char* Ws = ring + (u % NST) * W_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    bf16x8 xf[4], wf[4];
+    auto reads = [&](int kk) {
       const int c = kk * 4 + fq;
-      bf16x8 xf[4], wf[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = j * 16 + fr + tap;
@@ -317,12 +318,21 @@ __global__ __launch_bounds__(256) void convpos_split_kernel(ConvPosArgs a) {
         const int row = i * 16 + fr;
         wf[i] = *(const bf16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
+    };
+    auto mfmas = [&]() {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
+    };
+    // the first half's fragment reads go out before the weight DMAs of round u + NST - 1 (K-step order: gemm_bf16.hip)
+    if (live) reads(0);
+    if (u + NST - 1 < 8) stage_w((u + NST - 1) % NST, u + NST - 1);
+    if (!live) break;
+    mfmas();
+    reads(1);
+    mfmas();
   }
 
   if constexpr (TRC) ts[5] = __builtin_amdgcn_s_memtime();

@@ -240,29 +240,40 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
     else wait_stages<LPT, 0>(nst);
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
     if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
-    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
+    // Order inside a K-step: the tile's fragment reads FIRST, then the LDS-DMAs of tile kt + NSTAGE - 1, then the MFMAs.
+    // A DMA instruction costs the wave 100-185 cycles of issue while the CU's address path is busy (all waves of the CU
+    // stage right behind the same barrier); issued ahead of the ds_reads -- the order of rounds 1-2 -- that stall delayed
+    // the reads and, behind them, every MFMA of the step.  Now the reads are in flight under the DMA issue and the MFMAs
+    // start the moment it ends: C2 44.4 -> 43.1 ms per pass (FF2 -0.9 us, QKV / FF1 / out-proj -0.3 us each per launch;
+    // variants measured: DMAs after the first half's MFMAs or after all MFMAs: +-0; under the second half's reads or between
+    // the halves' MFMAs: the same gain within 0.1 ms; every DMA followed by its share of the MFMAs: +2.5 ms; DESIGN 4
+    // "K-step order").
+    const bool more = kt + NSTAGE - 1 < KT;
     const char* As = ring + buf * STAGE;
     const char* Ws = As + A_BYTES;
+    bf16x8 xf[BK / 32][TM], wf[BK / 32][TN];
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8 xf[TM], wf[TN];
       const int c = kk * 4 + fq;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm0 + j * 16 + fr;
-        xf[j] = *(const bf16x8*)(As + row * ROWB + ((c ^ swz(row)) << 4));
+        xf[kk][j] = *(const bf16x8*)(As + row * ROWB + ((c ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn0 + i * 16 + fr;
-        wf[i] = *(const bf16x8*)(Ws + row * ROWB + ((c ^ swz(row)) << 4));
+        wf[kk][i] = *(const bf16x8*)(Ws + row * ROWB + ((c ^ swz(row)) << 4));
       }
+    }
+    if (more) stage(nbuf, kt + NSTAGE - 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
     buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }

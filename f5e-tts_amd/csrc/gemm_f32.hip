@@ -203,12 +203,10 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
     const char* As = smem32 + buf * STAGE;
     const char* Ws = As + A_BYTES;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 xf[TM], wf[TN];
+    f32x4 xf[TM], wf[TN];
+    auto reads = [&](int g) {
       const int c = g * 4 + fq;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
@@ -220,6 +218,14 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(Gemm32Args a) {
         const int row = wn0 + i * 16 + fr;
         wf[i] = *(const f32x4*)(Ws + row * ROWB + ((c ^ (row & 15)) << 4));
       }
+    };
+    // the first fragment reads go out BEFORE the next tile's LDS-DMAs: a DMA costs the wave 100+ cycles of issue while the
+    // CU's address path is busy, and reads issued behind it (the order of rounds 1-2) wait that long (gemm_bf16.hip)
+    reads(0);
+    if (kt + NSTAGE - 1 < KT) stage(nbuf, kt + NSTAGE - 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g > 0) reads(g);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
