@@ -14,6 +14,8 @@
 //     The LDS image is lane-linear; the bank swizzle (16-B chunk ^ ((row>>1)&7)) is applied to the
 //     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
 //     16-lane ds_read_b128 groups are conflict free.
+#include <cstdlib>
+
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
 
@@ -91,13 +93,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
   // consecutive logical ids (= one XCD's L2) share the LARGER operand's panel: the weight panel when N*K >= M*K
   // (small batch), the activation panel when M > N (large batch: otherwise A is re-fetched once per n-panel)
+  // (small batch, m_major <= 0): COLUMN GROUPS of G = 2^-m_major n-tiles -- all row tiles of n-tiles [g G, (g + 1) G), n
+  // fastest, then the next group -- so that the contiguous run of logical ids one XCD owns is a (rows x G columns) block of
+  // tiles instead of whole n-panels: its private L2 then pulls (rows + G) 64-row panels through the fabric instead of
+  // (tiles_m + n-panels).  G is picked on the host (pick_group_shift); G = 1 is the plain n-major walk.
   int tile_m, tile_n;
-  if (a.m_major) {
+  if (a.m_major > 0) {
     tile_m = div_magic(bid, a.tiles_n, a.tile_magic);
     tile_n = bid - tile_m * a.tiles_n;
   } else {
-    tile_n = div_magic(bid, a.tiles_m, a.tile_magic);
-    tile_m = bid - tile_n * a.tiles_m;
+    const int sh = -a.m_major, per = a.tiles_m << sh;
+    const int g = div_magic(bid, per, a.tile_magic);
+    const int r = bid - g * per;
+    tile_m = r >> sh;
+    tile_n = (g << sh) + (r & ((1 << sh) - 1));
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -482,13 +491,60 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   }
 }
 
+// Column-group width (as a shift) for the n-major tile walk of a tiles_m x tiles_n grid whose logical ids are dealt to the 8
+// XCDs in contiguous runs (the kernel's bijection): the G = 2^s (dividing tiles_n) that minimises the number of distinct
+// 64-row operand panels (A row tiles + W column tiles) summed over the XCDs' runs -- what their private L2s fetch through
+// the fabric.  At M = 938: out-proj / FF2 (15 x 16 tiles) G = 4: 8 + 4 panels per XCD instead of 15 + 2; FF1 (15 x 32) G = 8.
+// A few hundred integer operations; memoised per thread for the eager launch path.
+inline int pick_group_shift(int tiles_m, int tiles_n, int bm, int bn) {
+  struct Memo { int tm, tn, bm, bn, s; };
+  static thread_local Memo memo[4] = {};
+  static thread_local int next = 0;
+  for (const Memo& e : memo)
+    if (e.tm == tiles_m && e.tn == tiles_n && e.bm == bm && e.bn == bn) return e.s;
+#ifdef F5E_TOOLS
+  if (const char* f = getenv("F5E_GEMM_GROUP_SHIFT")) {   // diagnostics build only: A/B of the walk
+    const int s = atoi(f);
+    if (s >= 0 && s <= 4 && tiles_n % (1 << s) == 0) return s;
+  }
+#endif
+  const int n = tiles_m * tiles_n, q8 = n >> 3, r8 = n & 7;
+  long best = -1;
+  int best_s = 0;
+  for (int s = 0; s <= 4 && (tiles_n % (1 << s)) == 0 && (1 << s) <= tiles_n; ++s) {
+    long cost = 0;
+    int id = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int cnt = q8 + (x < r8 ? 1 : 0);
+      unsigned long long seen_m[4] = {}, seen_n[4] = {};   // up to 256 tiles per side
+      for (int i = 0; i < cnt; ++i, ++id) {
+        const int per = tiles_m << s, g = id / per, r = id - g * per;
+        const int tm = r >> s, tn = (g << s) + (r & ((1 << s) - 1));
+        seen_m[(tm >> 6) & 3] |= 1ull << (tm & 63);
+        seen_n[(tn >> 6) & 3] |= 1ull << (tn & 63);
+      }
+      for (int w = 0; w < 4; ++w) cost += (long)__builtin_popcountll(seen_m[w]) * bm + (long)__builtin_popcountll(seen_n[w]) * bn;
+    }
+    if (best < 0 || cost < best) { best = cost; best_s = s; }
+  }
+  memo[next] = Memo{tiles_m, tiles_n, bm, bn, best_s};
+  next = (next + 1) & 3;
+  return best_s;
+}
+
 template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  a.m_major = a.M > a.N;
-  a.tile_magic = div_magic_of(a.m_major ? a.tiles_n : a.tiles_m);
+  if (a.M > a.N) {
+    a.m_major = 1;
+    a.tile_magic = div_magic_of(a.tiles_n);
+  } else {
+    const int sh = (a.tiles_m <= 256 && a.tiles_n <= 256) ? pick_group_shift(a.tiles_m, a.tiles_n, BM, BN) : 0;
+    a.m_major = -sh;
+    a.tile_magic = div_magic_of(a.tiles_m << sh);
+  }
   a.rps_magic = div_magic_of(a.rows_per_seq);
   a.n_main = a.tiles_m * a.tiles_n;
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once

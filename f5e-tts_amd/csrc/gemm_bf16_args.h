@@ -15,8 +15,8 @@ struct GemmArgs {
   const bf16* A; const bf16* W;
   int lda, ldw;
   int M, N, K;
-  int tiles_m, tiles_n, m_major;
-  unsigned tile_magic;   // floor(2^32 / (m_major ? tiles_n : tiles_m)): tile decode without a division (div_magic)
+  int tiles_m, tiles_n, m_major;   // m_major: 1 = row-major tile walk; <= 0: n-major in column groups of 2^-m_major n-tiles
+  unsigned tile_magic;   // floor(2^32 / (m_major > 0 ? tiles_n : tiles_m << -m_major)): tile decode without a division (div_magic)
   int rows_per_seq;
   unsigned rps_magic;    // floor(2^32 / rows_per_seq)
   int n_main;            // tiles_m * tiles_n: workgroups beyond it only prefetch (F5ePrefetch), 64x64 .. 128x128 kernels

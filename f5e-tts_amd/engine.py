@@ -651,26 +651,36 @@ def _loop_state(engine: DiTEngine, key: tuple, persistent: bool) -> Tuple[_LoopS
     return _LoopState(), True
 
 
-def _publish_state(engine: DiTEngine, key: tuple, st: _LoopState) -> None:
-    """Insert a fully built state and evict least-recently-used ones beyond LOOP_CACHE_ENTRIES entries or
-    LOOP_CACHE_BYTES of device memory.  This runs on the CAPTURE stream, so evicted graphs are only queued here
-    (engine._loops.pending); CFM._integrate parks them behind an event on the CALLER's stream (retire_pending) -- an event
-    recorded on a stream that later captures would be polled by other threads' Graph.reap() during that capture, which
-    invalidates it."""
-    # pooled states share one buffer per thread (_Pool): what a cached state costs is its graphs, not device memory
-    st.nbytes = 0 if st.pool is not None else sum(t.numel() * t.element_size() for t in st.buf.values() if isinstance(t, Tensor))
-    cache = engine._loops.cache
-    cache[key] = st
+def _cache_bytes(cache: dict) -> int:
+    """Device memory pinned by a thread's cached loop states: every DISTINCT pool block once (all states of one (thread,
+    stream) are carved from the same block) plus the private buffers of un-pooled states."""
+    pools = {id(x.pool): x.pool.buf.numel() for x in cache.values() if x.pool is not None}
+    return sum(pools.values()) + sum(x.nbytes for x in cache.values() if x.pool is None)
+
+
+def _pending_list(engine: DiTEngine) -> list:
     pending = getattr(engine._loops, "pending", None)
     if pending is None:
         pending = engine._loops.pending = []
-    while len(cache) > 1 and (len(cache) > LOOP_CACHE_ENTRIES or sum(x.nbytes for x in cache.values()) > LOOP_CACHE_BYTES):
+    return pending
+
+
+def _publish_state(engine: DiTEngine, key: tuple, st: _LoopState) -> None:
+    """Insert a fully built state and evict least-recently-used ones beyond LOOP_CACHE_ENTRIES entries or
+    LOOP_CACHE_BYTES of device memory (_cache_bytes: a pool block counts once, whoever shares it).  Runs on the CALLER's
+    stream, outside any capture; evicted states are only queued here (engine._loops.pending) and run_ode parks their graphs
+    behind an event on that stream once the call's last launch is queued (retire_pending)."""
+    st.nbytes = 0 if st.pool is not None else sum(t.numel() * t.element_size() for t in st.buf.values() if isinstance(t, Tensor))
+    cache = engine._loops.cache
+    cache[key] = st
+    pending = _pending_list(engine)
+    while len(cache) > 1 and (len(cache) > LOOP_CACHE_ENTRIES or _cache_bytes(cache) > LOOP_CACHE_BYTES):
         pending.append(cache.pop(next(iter(cache))))
 
 
 def retire_pending(engine: DiTEngine) -> None:
-    """Park the graphs of evicted loop states behind an event on the CURRENT stream and free the finished ones.  Call it on
-    the caller's stream after it has been ordered behind the capture stream (CFM._integrate), never while capturing."""
+    """Park the graphs of evicted loop states behind an event on the CURRENT stream and free the finished ones.  Runs on the
+    caller's stream (run_ode's last act; everything of a call executes there), never while capturing."""
     pending = getattr(engine._loops, "pending", None)
     while pending:
         pending.pop().retire()
@@ -735,6 +745,12 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
                 pools = engine._loops.pools = {}
             pool = pools.get(run_stream)          # one pool per (thread, stream): its users never overlap in time
             if pool is None or pool.buf.numel() < total:
+                if pool is not None:
+                    # superseded by a larger block: the cached states carved from the old one would keep it pinned (a
+                    # stream of growing shapes would hold several multi-GB blocks at once) -- drop them with it
+                    cache_ = getattr(engine._loops, "cache", {})
+                    for k_ in [k_ for k_, s_ in cache_.items() if s_.pool is pool]:
+                        _pending_list(engine).append(cache_.pop(k_))
                 pool = pools[run_stream] = _Pool(total + total // 4, dv)
             st.pool, base = pool, pool.buf
         else:
@@ -892,6 +908,9 @@ def run_ode(engine: DiTEngine, inp: SamplerInputs, use_graph: bool = True, want_
         enqueue(steps)
     if not want_trajectory:
         traj[1].copy_(y)
+    # graphs of loop states this call evicted: parked behind an event on this (the caller's) stream, after the call's last
+    # launch and outside any capture -- every caller of run_ode gets it, not only CFM._integrate
+    retire_pending(engine)
     # the state's buffers are rewritten by this thread's next call: hand back a copy (6 MB at C2, a few us)
     return traj.clone() if persistent else traj
 

@@ -85,7 +85,8 @@ def total_mel_len(ref_mel_len: int, prompt_text: str, gt_text: str, speed: float
 def c4_work_list(csv_path: str, need: int) -> List[Tuple[int, int]]:
     """(ref frames, total frames) of `need` utterances, taken cyclically from a `ref_secs,ref_bytes,gen_secs,gen_bytes`
     table (tests/golden/c4_durations.csv: the duration / byte-count columns of the reference's LibriSpeech-PC
-    cross-sentence list) with the reference's length rule (eval/utils_eval.py:147-161, prompt text + one space)."""
+    cross-sentence list) with the reference's length rule (eval/utils_eval.py:147-161; the prompt text gains a trailing
+    space, :130-131, and the LibriSpeech list reader hands the target text over with a leading one, :57)."""
     rows = []
     with open(csv_path) as f:
         for line in f:
@@ -93,7 +94,7 @@ def c4_work_list(csv_path: str, need: int) -> List[Tuple[int, int]]:
                 continue
             rs, rb, _gs, gb = line.split(",")
             ref_len = int(float(rs) * 24000) // 256
-            rows.append((ref_len, ref_len + int(ref_len / (int(rb) + 1) * int(gb))))
+            rows.append((ref_len, ref_len + int(ref_len / (int(rb) + 1) * (int(gb) + 1))))
     return [rows[i % len(rows)] for i in range(need)]
 
 
@@ -117,6 +118,105 @@ def reduce_job_totals(dist, frames: float, gen_frames: float, seconds: float, de
                 world_size=world, backend=dist.get_backend())
 
 
+# ----------------------------------------------------------------------------- in-rank concurrency
+
+class RankWorkers:
+    """K host threads of ONE rank, each with its own HIP stream, pulling utterances off a shared cursor.
+
+    Why: at batch 1 the block kernels are latency-bound (M = 2 N rows fill ~16 % of the GEMM roofline), so
+    independent utterances in flight on separate streams overlap each other's launch gaps -- the MI355X counterpart of the
+    reference's thread pool over chunks (infer/utils_infer.py:511) and of its per-rank batches (eval_infer_batch.py:187-216).
+    Every utterance is still one `sample` call with its own seed, so each output is bit-identical to the sequential run
+    whichever worker takes it (tests/test_e2e_gpu.py).  The threads persist for the object's life: the samplers' loop
+    states (buffers, captured graphs) are keyed by (thread, stream), and a warm-up through the same object is what warms
+    the timed run.  `workers` <= 1: plain loop on the caller's thread and current stream."""
+
+    def __init__(self, workers: int = 1, device=None):
+        import threading
+        self.workers = max(1, int(workers))
+        self.device = device
+        self._tls = threading.local()
+        self._pool = None
+        if self.workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="f5e-rank-worker")
+
+    def _stream_ctx(self):
+        import contextlib
+        if not torch.cuda.is_available():
+            return contextlib.nullcontext()
+        st = getattr(self._tls, "stream", None)
+        if st is None:
+            st = self._tls.stream = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(st)
+
+    def map(self, fn, items: Sequence) -> List:
+        """[fn(x) for x in items], in input order; with K > 1 the calls are spread over the worker threads (dynamic: a
+        free worker takes the next item).  Returns after every worker's stream has drained.  The first exception stops
+        the hand-out and is re-raised."""
+        items = list(items)
+        if self._pool is None:
+            return [fn(x) for x in items]
+        import threading
+        results, errors = [None] * len(items), []
+        cursor, lock = [0], threading.Lock()
+
+        def drain(_):
+            with self._stream_ctx():
+                while True:
+                    with lock:
+                        i = cursor[0]
+                        cursor[0] += 1
+                    if i >= len(items) or errors:
+                        break
+                    try:
+                        results[i] = fn(items[i])
+                    except BaseException as e:  # noqa: BLE001  (re-raised on the caller's thread)
+                        errors.append(e)
+                        break
+                if torch.cuda.is_available():
+                    torch.cuda.current_stream(self.device).synchronize()
+
+        list(self._pool.map(drain, range(self.workers)))
+        if errors:
+            raise errors[0]
+        return results
+
+    def warm(self, fn, items: Sequence, rounds: int = 1) -> None:
+        """Every worker thread runs fn over ALL of `items`, `rounds` times, behind a common barrier: deterministic per-thread
+        warm-up (stream, allocator pool, loop states) -- a plain map() would leave it to chance which thread saw what."""
+        items = list(items)
+        if self._pool is None:
+            for _ in range(rounds):
+                for x in items:
+                    fn(x)
+            return
+        import threading
+        gate = threading.Barrier(self.workers)
+
+        def each(_):
+            gate.wait()
+            with self._stream_ctx():
+                for _r in range(rounds):
+                    for x in items:
+                        fn(x)
+                if torch.cuda.is_available():
+                    torch.cuda.current_stream(self.device).synchronize()
+
+        list(self._pool.map(each, range(self.workers)))
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 # ----------------------------------------------------------------------------- distributed driver
 
 def shard(items: Sequence, costs: Sequence[float], rank: int, world: int, mode: str = "lpt") -> List:
@@ -126,17 +226,18 @@ def shard(items: Sequence, costs: Sequence[float], rank: int, world: int, mode: 
 
 
 def run_sharded(work: Sequence[Tuple[str, int, int]], process_one, rank: int, world: int, dist=None,
-                mode: str = "lpt") -> dict:
+                mode: str = "lpt", workers: int = 1) -> dict:
     """``work``: (utt id, ref frames, total frames).  ``process_one(item)`` generates + writes one utterance.
+    ``workers`` > 1: that many host threads of this rank, one HIP stream each, take the rank's utterances off a shared
+    cursor (RankWorkers; process_one must be thread-safe -- the samplers are).
     Returns the whole-job totals after the closing all-reduce (works with any backend, incl. gloo on CPU)."""
     mine = shard(list(work), [flop_fwd(w[2]) for w in work], rank, world, mode)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    frames = 0
-    for item in mine:
-        process_one(item)
-        frames += item[2]
+    with RankWorkers(workers) as pool:
+        pool.map(process_one, mine)          # returns after every worker's stream has drained
+    frames = sum(item[2] for item in mine)
     elapsed = time.perf_counter() - t0
     done = [w[0] for w in mine]
     if dist is not None:
@@ -160,6 +261,9 @@ def main(argv=None):
     p.add_argument("--vocoder_path", default="pretrained_models/vocos-mel-24khz")
     p.add_argument("--output_dir", default="")
     p.add_argument("--partition", default="lpt", choices=["lpt", "contiguous"])
+    p.add_argument("--workers", default=4, type=int,
+                   help="host threads per rank, one HIP stream each, sampling independent utterances concurrently "
+                        "(outputs are bit-identical to --workers 1; 1 = the reference's one-utterance-at-a-time loop)")
     # the three drivers of the reference in one: eval_infer_batch.py (cfg), eval_infer_batch_tts.py (-as/-at) and
     # eval_infer_batch_vc.py (-as/-ap; PPG read from --ppg_dir/<gen_utt>.npy, the wenet extractor is SURVEY row f3)
     p.add_argument("--mode", default="cfg", choices=["cfg", "tts", "vc"])
@@ -219,7 +323,9 @@ def main(argv=None):
     with open(args.testset, "r", encoding="utf-8") as f:
         for line in f:
             ref_utt, _rd, ref_txt, gen_utt, _gd, gen_txt = line.rstrip("\n").split("\t")
-            rows.append((ref_utt, ref_txt, gen_utt, gen_txt))
+            # the reference's LibriSpeech-PC list reader prepends a space to the target text (eval/utils_eval.py:57); it
+            # counts in the duration rule and shows up as a token between prompt and target
+            rows.append((ref_utt, ref_txt, gen_utt, " " + gen_txt))
     # cheap metadata pass (wav headers only) so that every rank can build the same partition without decoding audio
     import wave
     work, meta = [], {}
@@ -291,7 +397,7 @@ def main(argv=None):
             wav = wav * rms / U.target_rms
         U.save_wav(os.path.join(out_dir, f"{utt}.wav"), wav[0].cpu().numpy(), U.target_sample_rate)
 
-    res = run_sharded(work, process_one, rank, world, dist if world > 1 else None, args.partition)
+    res = run_sharded(work, process_one, rank, world, dist if world > 1 else None, args.partition, workers=args.workers)
     if rank == 0:
         print(f"Done batch inference in {res['seconds'] / 60:.2f} minutes: {res['frames'] / res['seconds']:.1f} "
               f"mel-frames/s on {world} GPU(s).")

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _C
-from ..engine import SamplerInputs, h2d, ode_setup, retire_pending, run_ode
+from ..engine import SamplerInputs, h2d, ode_setup, run_ode
 from .modules import MelSpec
 from .utils import default, exists, intersperse, lens_to_mask, list_str_to_idx, list_str_to_tensor
 
@@ -150,9 +150,6 @@ class CFM(nn.Module):
                 side = self._tls.stream = torch.cuda.Stream(device=eng.device)
             setup = ode_setup(eng, inp)   # pinned uploads + shared tables on the caller's stream, see ode_setup
             trajectory = run_ode(eng, inp, use_graph=True, chains=self.chains, setup=setup, capture_stream=side)
-            # graphs of loop states evicted by this call: parked behind an event on the CALLER's stream, never on the
-            # stream that captures (engine._publish_state)
-            retire_pending(eng)
         else:
             trajectory = run_ode(eng, inp, use_graph=False, timer=self.kernel_timer, chains=self.chains)
         self.transformer.clear_cache()

@@ -421,6 +421,72 @@ def make_callers_case(ref_root, cfm_mod):
     print("wrote", path)
 
 
+def make_eval_case(ref_root, cfm_mod):
+    """Integer / index callers of the eval driver, captured from the reference's own eval/utils_eval.py:77-219
+    (get_inference_prompt: trailing-space rule, total_mel_len, bucket index, flush order, residual buckets, the seed-666
+    shuffle) and model/utils.py:270-311 (convert_char_to_pinyin) on ASCII input.  Audio loading is stubbed (the prompt
+    "file name" encodes length and seed), the mel is the reference's own MelSpec over the torchaudio shim; what is captured
+    is data: utterance order per batch, frame counts, token lists.  jieba's segmentation of single-byte text is the shim's
+    restatement (third party, unpinned); everything the REFERENCE does around it is pinned here."""
+    import json
+    load_reference_infer(ref_root, cfm_mod)          # installs the remaining import shims (pydub, vocos, ...)
+    tr = sys.modules["transformers"]
+    tr.WhisperProcessor = tr.WhisperForConditionalGeneration = object
+    ev = types.ModuleType("f5_tts.eval")
+    ev.__path__ = [os.path.join(ref_root, "src", "f5_tts", "eval")]
+    sys.modules["f5_tts.eval"] = ev
+    ec = types.ModuleType("f5_tts.eval.ecapa_tdnn")
+    ec.ECAPA_TDNN_SMALL = object
+    sys.modules["f5_tts.eval.ecapa_tdnn"] = ec
+    if "tqdm" not in sys.modules:
+        import tqdm  # noqa: F401
+    ta = sys.modules["torchaudio"]
+
+    def fake_load(path):      # "<anything>/n<samples>_s<seed>_a<amp in 1/1000>.wav"
+        name = os.path.basename(path)[:-4]
+        n, sd_, amp = (int(x[1:]) for x in name.split("_"))
+        g = torch.Generator().manual_seed(sd_)
+        return amp / 1000.0 * torch.randn(1, n, generator=g), 24000
+
+    ta.load = fake_load
+    UE = importlib.import_module("f5_tts.eval.utils_eval")
+    UM = sys.modules["f5_tts.model.utils"]
+    rows = [ln.strip().split(",") for ln in open(os.path.join(HERE, "c4_durations.csv")) if ln[0] != "#" and ln.strip()]
+    rng = np.random.default_rng(4242)
+
+    def ascii_text(nbytes, punct):
+        words = []
+        while sum(len(w) + 1 for w in words) < nbytes + 8:
+            words.append("".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz"), size=int(rng.integers(1, 9)))))
+        t = " ".join(words)[:max(1, nbytes - 1)].rstrip()
+        return (t[0].upper() + t[1:] + punct)[:nbytes] if nbytes > 1 else "a"
+
+    meta = []
+    for i, (rs, rb, gs, gb) in enumerate(rows[:72]):
+        n = int(float(rs) * 24000)
+        ptxt = ascii_text(int(rb), ".;'" [i % 3] if i % 5 else "")      # some prompts end in a letter, ';' is translated
+        gtxt = ascii_text(int(gb), ".")
+        if i % 7 == 0:
+            gtxt = gtxt.replace(" ", "; ", 1).replace("a", "it's ", 1)
+        meta.append((f"utt{i:03d}", ptxt, f"/nowhere/n{n}_s{1000 + i}_a{30 + 40 * (i % 4)}.wav", " " + gtxt, ""))
+    out = {"meta": [[u, p, w, g] for u, p, w, g, _ in meta], "cases": []}
+    for bs, nb in ((1, 200), (3000, 200), (2500, 16)):
+        pr = UE.get_inference_prompt(meta, infer_batch_size=bs, num_buckets=nb)
+        out["cases"].append({"infer_batch_size": bs, "num_buckets": nb,
+                             "batches": [{"utts": list(b[0]), "ref_mel_lens": [int(x) for x in b[3]],
+                                          "total_mel_lens": [int(x) for x in b[4]],
+                                          "mel_shape": list(b[2].shape), "ref_rms": [float(x) for x in b[1]],
+                                          "tokens_first": b[5][0]} for b in pr]})
+    out["pinyin_ascii"] = []
+    for t in ("end.Next one;ok", "it's 2 fast", "Hello, World!  Two  spaces", "a;b;c", "x", "Numbers 123 and-dashes_under",
+              'Quote "this" and that: ok', meta[0][1] + " " + meta[0][3]):
+        out["pinyin_ascii"].append({"text": t, "tokens": UM.convert_char_to_pinyin([t])[0]})
+    path = os.path.join(HERE, "eval_prompts.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, [len(c["batches"]) for c in out["cases"]])
+
+
 def make_unett_case():
     """Reference UNetT.forward (backbones/unett.py) on two small seeded configs."""
     unett_mod = importlib.import_module("f5_tts.model.backbones.unett")
@@ -625,6 +691,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "callers":
         make_callers_case(ref, cfm_mod)
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "eval":
+        make_eval_case(ref, cfm_mod)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "vq":
         make_vq_case(modules_mod)
         return
@@ -653,6 +722,7 @@ def main():
                   n_ppg=21, mode="vc")
     make_prep_case(cfm_mod, dit_mod)
     make_callers_case(ref, cfm_mod)
+    make_eval_case(ref, cfm_mod)
     make_vq_case(modules_mod)
     make_unett_case()
     make_stft_case(ref)

@@ -103,3 +103,75 @@ def test_preprocess_ref_audio_text_and_resampled_reference(tmp_path):
     U.remove_silence_for_generated_wav(out)
     g, _ = U.load_wav(out)
     assert abs(g.shape[1] / 24000 - 3.0) < 0.03                  # 2 s pause -> 2 x 500 ms kept
+
+
+# ------------------------------------------------------------------ cross-checks against independent implementations
+# PARITY UNPINNED: the reference delegates resampling to torchaudio and silence handling to pydub (neither vendored, neither
+# in this image), so no reference-held vector exists.  What follows holds the restatements to (a) an independent polyphase
+# resampler that IS in the image (scipy.signal.resample_poly) and (b) range lists worked out by hand from pydub's published
+# algorithm on waveforms whose edges sit on millisecond boundaries (reference call sites: infer/utils_infer.py:274-361, 445).
+
+@pytest.mark.parametrize("orig,new", [(16000, 24000), (48000, 24000), (44100, 24000), (22050, 24000), (24000, 16000)])
+def test_resample_agrees_with_scipy_resample_poly_on_band_limited_noise(orig, new):
+    """Noise band-limited to 0.7 of the lower Nyquist frequency (both filters' passband): the width-6 Hann-windowed sinc of
+    torchaudio's default against scipy's Kaiser(14) polyphase filter.  Stated bound: SNR >= 45 dB and max deviation
+    <= 2e-3 of full scale away from the zero-padded edges (measured 49.7-53.3 dB, 0.5-1.2e-3)."""
+    from scipy import signal
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(orig)
+    x = signal.sosfiltfilt(signal.butter(10, 0.7 * min(orig, new) / 2, fs=orig, output="sos"), x)
+    x = (0.3 * x / np.abs(x).max()).astype(np.float32)
+    y = A.resample(torch.from_numpy(x)[None], orig, new)[0].numpy()
+    g = math.gcd(orig, new)
+    r = signal.resample_poly(x.astype(np.float64), new // g, orig // g, window=("kaiser", 14.0))
+    assert len(y) == len(r) == math.ceil(len(x) * new / orig)
+    core = slice(400, len(y) - 400)
+    err = y[core] - r[core]
+    snr = 10 * np.log10((r[core] ** 2).mean() / (err ** 2).mean())
+    assert snr >= 45.0 and np.abs(err).max() <= 2e-3, (snr, np.abs(err).max())
+
+
+def _blocks(sr, *spans):
+    """Concatenation of (milliseconds, amplitude) blocks; a sounding block is +-amp alternating (every sample has the same
+    magnitude, so a window's rms does not depend on where a period starts)."""
+    out = []
+    for ms, amp in spans:
+        n = sr * ms // 1000
+        out.append(amp * (1.0 - 2.0 * (np.arange(n) % 2)))
+    return np.concatenate(out).astype(np.float32)
+
+
+def test_silence_rules_on_hand_built_waveform_with_known_edges():
+    """silence 0-700 ms | sound 700-1900 | silence 1900-3400 | sound 3400-4000 | silence 4000-4250, amplitude 0.5 (-6 dBFS).
+    By pydub's algorithm (a 1000 ms window is silent iff it lies wholly inside a silent stretch: one millisecond of the sound
+    puts it at -36 dBFS): detect_silence(1000 ms, -50 dB, step 1) = [[1900, 3400]] -- the 700 ms head and 250 ms tail are
+    shorter than the window -- and everything below follows from that by the published range arithmetic."""
+    sr = 24000
+    seg = A.Segment.from_float(_blocks(sr, (700, 0.0), (1200, 0.5), (1500, 0.0), (600, 0.5), (250, 0.0)), sr)
+    assert len(seg) == 4250
+    assert abs(seg[700:1900].dBFS - 20 * math.log10(0.5)) < 1e-3 and seg[0:700].dBFS == -float("inf")
+    assert A.detect_silence(seg, 1000, -50, 1) == [[1900, 3400]]
+    assert A.detect_nonsilent(seg, 1000, -50, 1) == [[0, 1900], [3400, 4250]]
+    # seek_step 10 (what the reference passes): starts 1900 .. 2400 in steps of 10 -> the same range
+    assert A.detect_silence(seg, 1000, -50, 10) == [[1900, 3400]]
+    # min_silence_len 100: head [0, 700], pause, tail [4000, 4250]
+    assert A.detect_silence(seg, 100, -50, 1) == [[0, 700], [1900, 3400], [4000, 4250]]
+    assert A.detect_nonsilent(seg, 100, -50, 1) == [[700, 1900], [3400, 4000]]
+    # split_on_silence: keep 500 ms -> [-500, 2400] and [2900, 4750], no overlap, clipped to the segment
+    parts = A.split_on_silence(seg, 1000, -50, 500, 1)
+    assert [len(p) for p in parts] == [2400, 4250 - 2900]
+    assert np.array_equal(parts[0].pcm, seg[0:2400].pcm) and np.array_equal(parts[1].pcm, seg[2900:4250].pcm)
+    # keep 1000 ms -> [-1000, 2900] and [2400, 5250] overlap: both meet at (2900 + 2400) // 2 = 2650
+    parts = A.split_on_silence(seg, 1000, -50, 1000, 1)
+    assert [len(p) for p in parts] == [2650, 4250 - 2650]
+    # remove_silence_for_generated_wav (utils_infer.py:567-575): 1000 ms / -50 dB / keep 500 / step 10
+    assert len(A.strip_generated_silence(seg)) == 2400 + 1350
+    # edges (utils_infer.py:273-287): leading silence in 10 ms chunks at -42 dB -> 700; trailing per millisecond -> 250
+    assert A.detect_leading_silence(seg, -42.0) == 700
+    assert abs(len(A.remove_silence_edges(seg)) - 3300) <= 1        # `end -= 0.001` 250 times: float accumulation, +-1 ms
+    # preprocess_ref_audio_text's clip (utils_infer.py:295-330) on a clip under 12 s: nothing cut, edges stripped, 50 ms added
+    assert abs(len(A.clip_reference(seg)) - (3300 + 50)) <= 1
+    # a threshold between the two levels: quiet sound (-46 dBFS) counts as silence at -42 but not at -50
+    quiet = A.Segment.from_float(_blocks(sr, (300, 0.005), (1000, 0.5), (200, 0.005)), sr)
+    assert A.detect_leading_silence(quiet, -42.0) == 300 and A.detect_leading_silence(quiet, -50.0) == 0
+    assert abs(len(A.remove_silence_edges(quiet, -42)) - 1000) <= 1

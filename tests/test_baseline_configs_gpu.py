@@ -9,7 +9,9 @@
   C5  configs/F5TTS_Small_PPG.yaml (dim 768, 18 blocks, PPG input, codebook keys), sample_vc, NFE 32 -> vs the fp32 oracle
 
 Tolerances (stated, bf16 MFMA contractions against an fp32 oracle through 22 x 32 or 18 x 96 network evaluations):
-relative L2 of the generated mel frames <= 1e-2, maximum absolute error <= 5 % of the mel's dynamic range, and the
+relative L2 of the generated mel frames <= 3e-3 at a config's own step count (measured 0.9-1.4e-3: a 2.5 x regression fails;
+round 3 stated 1e-2) and <= 5e-3 on the coarse 4-step grid of C3 (a) (its four large steps carry 2.1-2.7e-3), maximum
+absolute error <= 5 % of the mel's dynamic range, and the
 per-step error along the trajectory may not blow up (each step <= 4 x the previous one + 1e-4: on the sway grid the
 step sizes grow, so early ratios of 2-3 are the plain accumulation of per-step rounding, an instability shows as 10 x).
 The oracle legs cost ~15 s (C2), ~5 s (C3), ~15 s (C4), ~15 s (C5) of host CPU."""
@@ -24,7 +26,8 @@ from tools import synth as SY
 
 pytestmark = pytest.mark.gpu
 
-TOL_REL_L2 = 1e-2
+TOL_REL_L2 = 3e-3         # at the config's own NFE (16 / 32 steps)
+TOL_COARSE_GRID = 5e-3    # the 4-step grid of test_c3_batch32_items_equal_their_batch1_runs_and_the_oracle
 TOL_MAXABS_OF_RANGE = 0.05
 
 
@@ -50,11 +53,11 @@ def vocoder():
     return vs, voc.cuda().eval()
 
 
-def check_trajectory(traj, ref_traj, n_ref, what):
+def check_trajectory(traj, ref_traj, n_ref, what, tol=TOL_REL_L2):
     steps = ref_traj.shape[0] - 1
     errs = [rel_l2(traj[i][:, n_ref:], ref_traj[i][:, n_ref:]) for i in range(1, steps + 1)]
     print(f"{what}: per-step rel L2 (generated frames):", " ".join("%.1e" % e for e in errs))
-    assert errs[-1] < TOL_REL_L2, (what, errs[-1])
+    assert errs[-1] < tol, (what, errs[-1])
     assert all(b < 4.0 * a + 1e-4 for a, b in zip(errs, errs[1:])), (what, errs)
     return errs
 
@@ -102,13 +105,13 @@ def test_c3_batch32_items_equal_their_batch1_runs_and_the_oracle():
         one, _ = cfm.sample(wav[i:i + 1].cuda(), text[i:i + 1], **kw)
         e = rel_l2(full[i, n_ref:], one[0, n_ref:])
         worst = max(worst, e)
-        assert e < TOL_REL_L2, (i, e)
+        assert e < TOL_COARSE_GRID, (i, e)
         assert torch.equal(full[i, :n_ref], one[0, :n_ref])     # stitched reference frames: copied, never computed
     print("C3: worst item-vs-batch-1 rel L2 %.3e" % worst)
     i = 17
     ref_out, ref_traj = O.cfm_sample(sd, cfg, wav[i:i + 1], text[i:i + 1], None, **kw)
-    check_trajectory(ftraj[:, i:i + 1], ref_traj, n_ref, "C3 item 17 vs oracle")
-    assert rel_l2(full[i, n_ref:], ref_out[0, n_ref:]) < TOL_REL_L2
+    check_trajectory(ftraj[:, i:i + 1], ref_traj, n_ref, "C3 item 17 vs oracle", tol=TOL_COARSE_GRID)
+    assert rel_l2(full[i, n_ref:], ref_out[0, n_ref:]) < TOL_COARSE_GRID
 
 
 def test_c3_full_nfe32_batch32_vs_batch1_and_oracle():
@@ -226,9 +229,14 @@ def test_c4_eval_infer_batch_main_writes_the_oracles_audio(tmp_path):
     (tmp_path / "test.lst").write_text("\n".join(lst) + "\n")
     cfg_yaml = os.path.join(os.path.dirname(os.path.abspath(f5e_tts_amd.__file__)), "configs", "F5TTS_v1_Base.yaml")
     out_dir = tmp_path / "out"
-    E.main(["-n", "F5TTS_v1_Base", "-t", str(tmp_path / "test.lst"), "-nfe", "16", "-s", "0", "--ckpt",
-            str(tmp_path / "model.safetensors"), "--audio_root", str(audio), "--vocoder_path", str(vdir),
-            "--output_dir", str(out_dir), "-mc", cfg_yaml])
+    argv = ["-n", "F5TTS_v1_Base", "-t", str(tmp_path / "test.lst"), "-nfe", "16", "-s", "0", "--ckpt",
+            str(tmp_path / "model.safetensors"), "--audio_root", str(audio), "--vocoder_path", str(vdir), "-mc", cfg_yaml]
+    E.main(argv + ["--output_dir", str(out_dir), "--workers", "3"])   # three host threads, one stream each (RankWorkers)
+    # in-rank concurrency changes nothing: the files of the one-utterance-at-a-time loop are byte-identical
+    out_seq = tmp_path / "out_seq"
+    E.main(argv + ["--output_dir", str(out_seq), "--workers", "1"])
+    for utt, *_ in utts:
+        assert (out_dir / f"{utt}.wav").read_bytes() == (out_seq / f"{utt}.wav").read_bytes(), utt
     vocab, _ = get_tokenizer(U._DEFAULT_VOCAB)
     seen = []
     for j, (utt, path, ref_txt, gen_txt) in enumerate(utts):
@@ -238,6 +246,7 @@ def test_c4_eval_infer_batch_main_writes_the_oracles_audio(tmp_path):
         ref_len = a.shape[-1] // 256
         if len(ref_txt[-1].encode("utf-8")) == 1:
             ref_txt = ref_txt + " "
+        gen_txt = " " + gen_txt          # reference eval/utils_eval.py:57 (LibriSpeech-PC list reader)
         tot = E.total_mel_len(ref_len, ref_txt, gen_txt)
         seen.append(tot)
         assert got.shape[1] == 256 * (tot - ref_len - 1)

@@ -293,6 +293,69 @@ def test_bucketing_and_partitions():
     assert total_mel_len(187, "Some call me nature. ", "Hello world") == 187 + int(187 / 21 * 11)
 
 
+def test_eval_prompt_bucketing_and_ascii_tokens_equal_the_reference_capture():
+    """Integer / index work of the eval driver, bit-exact against tests/golden/eval_prompts.json -- captured by
+    make_golden.py from the reference's own get_inference_prompt (eval/utils_eval.py:77-219) and convert_char_to_pinyin
+    (model/utils.py:270-311): the trailing-space rule, total_mel_len, bucket index, flush order, residual buckets in bucket
+    order, the seed-666 shuffle -> the ORDERED batches; and the ASCII token lists."""
+    from f5e_tts_amd.eval.eval_infer_batch import bucket_batches, total_mel_len
+    from f5e_tts_amd.infer.utils_infer import convert_char_to_pinyin
+    gold = json.load(open(os.path.join(GOLD, "eval_prompts.json")))
+    utts, ref_lens, totals, texts = [], [], [], []
+    for utt, ptxt, wav, gtxt in gold["meta"]:
+        n = int(os.path.basename(wav)[:-4].split("_")[0][1:])
+        if len(ptxt[-1].encode("utf-8")) == 1:
+            ptxt = ptxt + " "
+        utts.append(utt)
+        ref_lens.append(n // 256)
+        totals.append(total_mel_len(n // 256, ptxt, gtxt))
+        texts.append(ptxt + gtxt)
+    for case in gold["cases"]:
+        want = [b["utts"] for b in case["batches"]]
+        got = bucket_batches(totals, infer_batch_size=case["infer_batch_size"], num_buckets=case["num_buckets"])
+        assert [[utts[i] for i in b] for b in got] == want, case["infer_batch_size"]
+        for b, idx in zip(case["batches"], got):
+            assert b["total_mel_lens"] == [totals[i] for i in idx] and b["ref_mel_lens"] == [ref_lens[i] for i in idx]
+            assert b["mel_shape"] == [len(idx), max(ref_lens[i] for i in idx) + 1, 100]
+            assert b["tokens_first"] == convert_char_to_pinyin([texts[idx[0]]])[0]
+    assert any(len(b["utts"]) > 1 for b in gold["cases"][1]["batches"])
+    for c in gold["pinyin_ascii"]:
+        assert convert_char_to_pinyin([c["text"]])[0] == c["tokens"], c["text"]
+
+
+def test_rank_workers_order_warmup_and_errors():
+    """eval_infer_batch.RankWorkers (the in-rank thread pool of the eval driver and of bench.py's C4 / concurrent legs):
+    results come back in input order, every item runs exactly once, warm() runs the whole list on EVERY worker thread,
+    the threads persist between calls (the samplers key their loop states by thread), an exception is re-raised."""
+    import threading
+    import time as _t
+    from f5e_tts_amd.eval.eval_infer_batch import RankWorkers, run_sharded
+    seen, lock = [], threading.Lock()
+
+    def fn(x):
+        _t.sleep(0.001 * (x % 3))
+        with lock:
+            seen.append((threading.get_ident(), x))
+        return x * x
+
+    with RankWorkers(3) as pool:
+        pool.warm(fn, [100, 101], rounds=2)
+        warm_threads = {t for t, _ in seen}
+        assert len(warm_threads) == 3 and len(seen) == 3 * 2 * 2           # every worker ran both items twice
+        assert all(sum(1 for t, x in seen if t == th and x == 100) == 2 for th in warm_threads)
+        seen.clear()
+        out = pool.map(fn, range(40))
+        assert out == [i * i for i in range(40)] and sorted(x for _, x in seen) == list(range(40))
+        assert {t for t, _ in seen} <= warm_threads                         # the same threads: their warm state is reused
+        with pytest.raises(ZeroDivisionError):
+            pool.map(lambda x: 1 // (x - 5), range(10))
+    assert RankWorkers(1).map(fn, [3, 4]) == [9, 16]                        # no pool: the caller's thread
+    work = [(f"u{i}", 10, 20 + i) for i in range(9)]
+    done = []
+    res = run_sharded(work, lambda it: done.append(it[0]), 0, 1, None, workers=3)
+    assert sorted(done) == sorted(w[0] for w in work) and res["frames"] == sum(w[2] for w in work)
+
+
 def _gloo_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)

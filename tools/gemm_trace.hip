@@ -143,6 +143,19 @@ int main(int argc, char** argv) {
          med(gap), med(ramp), med(span));
   printf("  per workgroup [cycles, median]: entry->prologue DMAs issued %.0f | +prefetch issued %.0f | entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
          med(dmaissue), med(issue), med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
+  {  // per-K-step profile (median over workgroups of the last launch): cycles from step kt's barrier to step kt+1's
+    const int l = L - 1, nk = std::min(KT, 36);
+    printf("  K-step profile [cycles]:");
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      std::vector<double> d;
+      for (int w = 0; w < grid; ++w) {
+        const unsigned long long* t = &h[((size_t)l * max_grid + w) * 48];
+        d.push_back((double)(t[4 + kt + 1] - t[4 + kt]));
+      }
+      printf(" %.0f", med(d));
+    }
+    printf("\n");
+  }
   if (variant == 10) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
     std::vector<double> a42, a43, a44, a45, a40;
     const int l = L - 1;
