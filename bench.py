@@ -99,6 +99,19 @@ def host_cpu_info():
     return info
 
 
+def stamped_ops(name):
+    """profiles/<name>.json (tools/prof_ops.py: per-op rocprofv3 summaries) when it was measured on the kernel sources that
+    run here (csrc hash), else (None, why)."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    if not os.path.exists(path):
+        return None, f"no profiles/{name}.json"
+    from tools.src_hash import csrc_sha256
+    j = json.load(open(path))
+    if j.get("csrc_sha256") != csrc_sha256():
+        return None, f"profiles/{name}.json was measured on other kernel sources (csrc_sha256 mismatch): refused"
+    return j["ops"], j.get("source")
+
+
 def median(v):
     s = sorted(v)
     return s[len(s) // 2]
@@ -510,6 +523,10 @@ def main():
                 if cands:
                     traffic, traffic_note = max(cands)[1], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources"
         d = per[dom]
+        # the committed rocprofv3 kernel-trace averages of the same workload (graph replay: no eager launch latency inside
+        # the interval) beside the live event brackets -- these are the figures that add up to ms_per_step
+        rp, rp_note = stamped_ops(f"ops_trace_{args.workload.lower()}")
+        pm, pm_note = stamped_ops(f"ops_pmc_{args.workload.lower()}")
         roofline = {"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": d["frac"], "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": KERNEL_OF[dom], "op": dom, "avg_launch_us": d["us"],
@@ -519,7 +536,16 @@ def main():
                     "all_ops_us": {k: v["us"] for k, v in per.items()},
                     "all_ops_frac": {k: v["frac"] for k, v in per.items()},
                     "gemm_flop_weighted_frac": weighted(per, gemms),
-                    "gemm_attn_flop_weighted_frac": weighted(per, list(per))}
+                    "gemm_attn_flop_weighted_frac": weighted(per, list(per)),
+                    "rocprof": None if rp is None else {
+                        "avg_launch_us": rp[dom]["avg_us"], "achieved": rp[dom]["tflops"], "frac": rp[dom]["frac"],
+                        "all_ops_us": {k: v["avg_us"] for k, v in rp.items()},
+                        "all_ops_frac": {k: v["frac"] for k, v in rp.items()},
+                        "block_sum_us": round(sum(v["avg_us"] for v in rp.values()), 2)},
+                    "rocprof_note": rp_note,
+                    "pmc_mfma": None if pm is None else {k: {x: v.get(x) for x in ("mfma_busy", "eff_clock_ghz", "wave_cycles_parked")}
+                                                         for k, v in pm.items()},
+                    "pmc_mfma_note": pm_note}
 
     roofline_c3 = None
     if (rank == 0 and world == 1 and args.workload == "C2" and not args.no_roofline and not args.no_c3):
@@ -587,6 +613,23 @@ def main():
         th.join()
         per3 = timed_eager_pass(c3_pass, 2 * B3 * N3, 2 * B3, N3, NFE)
         gem3 = [k for k in per3 if k != "ATTN"]
+        rp3, rp3_note = stamped_ops("ops_trace_c3")
+        pm3, pm3_note = stamped_ops("ops_pmc_c3")
+
+        def c3_op(k, v):
+            row = {"us": v["us"], "tflops": v["tflops"], "frac": v["frac"], "launches": v["launches"]}
+            if rp3 and k in rp3:       # rocprofv3 kernel-trace average of the same kernels (committed, hash-stamped)
+                row.update(rocprof_us=rp3[k]["avg_us"], frac_rocprof=rp3[k]["frac"])
+            if pm3 and k in pm3:       # matrix-pipe busy fraction and effective clock from the --pmc pass (same stamp)
+                row.update(mfma_busy=pm3[k].get("mfma_busy"), eff_clock_ghz=pm3[k].get("eff_clock_ghz"))
+            return row
+
+        def rp_weighted(names):
+            if not rp3 or any(k not in rp3 for k in names):
+                return None
+            fl = sum(op_flops(k, 2 * B3 * N3, 2 * B3, N3) for k in names)
+            return round(fl / sum(rp3[k]["avg_us"] * 1e-6 for k in names) / 1e12 / PEAK_BF16_TFLOPS, 4)
+
         roofline_c3 = {"workload": f"C3: batch {B3}, N_ref={R3} N={N3}, NFE={NFE}, CFG batched ({2 * B3 * N3} rows per launch)",
                        "mel_frames_per_sec": round(B3 * N3 / c3_s, 1), "pass_ms": round(c3_s * 1e3, 1),
                        "parity_vs_batch1_rel_l2": round(max(c3_par.values()), 6),
@@ -594,10 +637,11 @@ def main():
                                             "tolerance_rel_l2": TOL_REL_L2,
                                             "against": "the same items sampled at batch 1 (generated frames of the final mel)"},
                        "peak_tflops": PEAK_BF16_TFLOPS,
-                       "ops": {k: {"us": v["us"], "tflops": v["tflops"], "frac": v["frac"], "launches": v["launches"]}
-                               for k, v in per3.items()},
+                       "ops": {k: c3_op(k, v) for k, v in per3.items()},
                        "gemm_flop_weighted_frac": weighted(per3, gem3),
                        "gemm_attn_flop_weighted_frac": weighted(per3, list(per3)),
+                       "gemm_attn_flop_weighted_frac_rocprof": rp_weighted(list(per3)),
+                       "rocprof_note": rp3_note, "pmc_mfma_note": pm3_note,
                        "target_frac": 0.40, "timing": "median of per-launch HIP-event intervals, eager in-situ pass",
                        "under_load": power or None}
         log(f"roofline_c3: {roofline_c3['mel_frames_per_sec']} mel-frames/s, GEMM frac "

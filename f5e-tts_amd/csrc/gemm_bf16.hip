@@ -15,6 +15,7 @@
 //     per-lane SOURCE address and again on the ds_read_b128 (cdna guide 5.4 rule 21) -> the
 //     16-lane ds_read_b128 groups are conflict free.
 #include <cstdlib>
+#include <type_traits>
 
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
@@ -31,27 +32,37 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 
 template <int LPT, int EXTRA>
 __device__ __forceinline__ void wait_stages(int nst) {
+  // cases a kernel can reach satisfy nst * LPT + EXTRA <= 63 (static_assert at the call site); the clamp only keeps the
+  // unreachable instantiations assemblable (vmcnt is a 6-bit field)
+  constexpr auto C = [](int v) constexpr { return v > 63 ? 63 : v; };
   switch (nst) {
-    case 0: wait_vm_lgkm0<EXTRA>(); break;
-    case 1: wait_vm_lgkm0<LPT + EXTRA>(); break;
-    case 2: wait_vm_lgkm0<2 * LPT + EXTRA>(); break;
-    case 3: wait_vm_lgkm0<3 * LPT + EXTRA>(); break;
-    case 4: wait_vm_lgkm0<4 * LPT + EXTRA>(); break;
-    case 5: wait_vm_lgkm0<5 * LPT + EXTRA>(); break;
-    default: wait_vm_lgkm0<6 * LPT + EXTRA>(); break;
+    case 0: wait_vm_lgkm0<C(EXTRA)>(); break;
+    case 1: wait_vm_lgkm0<C(LPT + EXTRA)>(); break;
+    case 2: wait_vm_lgkm0<C(2 * LPT + EXTRA)>(); break;
+    case 3: wait_vm_lgkm0<C(3 * LPT + EXTRA)>(); break;
+    case 4: wait_vm_lgkm0<C(4 * LPT + EXTRA)>(); break;
+    case 5: wait_vm_lgkm0<C(5 * LPT + EXTRA)>(); break;
+    default: wait_vm_lgkm0<C(6 * LPT + EXTRA)>(); break;
   }
 }
 
 // K-step 64: 128-byte LDS rows, two rows per 256-byte bank line, swizzle (row >> 1) & 7.  (Measured and dropped, DESIGN 4:
 // K-step 128, 5-8 stage rings, 8 waves on the 64x64 tile, intra-workgroup split-K for the one-workgroup-per-CU launches.)
 // DBG == 3: in-kernel timestamps for tools/gemm_trace.hip (never instantiated by the library).
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
+// NLOAD > 0: ROLE SPLIT.  The workgroup gets NLOAD extra waves that do nothing but stage (every global_load_lds of the ring +
+// the counted vmcnt waits); the WGM x WGN consumer waves only ds_read and MFMA.  Why: the CU's texture-address path takes
+// ~18 cycles per 1 KiB LDS-DMA instruction (tools/l2_probe.hip: 57 B/clk per CU from L2, whatever the number of waves), so a
+// 64 x 64 K-step carries 288 cycles of DMA issue against 128 of MFMA -- and with every wave doing both, behind one barrier,
+// the two ADD (553 cycles per step measured).  Split, the loader's issue runs beside the consumers' reads and MFMAs.
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0>
+__global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                   // bytes per LDS row
   auto swz = [](int row) { return (row >> 1) & 7; };
-  constexpr int NT = 64 * WGM * WGN;  // WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
+  constexpr int NCW = WGM * WGN;      // WGM x WGN consumer waves, each owning a (BM/WGM) x (BN/WGN) sub-tile
+  constexpr int NC = 64 * NCW;
+  constexpr int NT = NLOAD ? 64 * NLOAD : NC;   // threads that stage: the loader waves of a role-split launch, else everyone
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -62,6 +73,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tid = (int)threadIdx.x;
+  const bool is_loader = NLOAD > 0 && wave >= NCW;       // wave-uniform
+  const int stid = NLOAD ? tid - NC : tid;               // index among the staging threads (loaders: 0 .. NT - 1)
+  const int swave = NLOAD ? wave - NCW : wave;
   unsigned long long* trc = nullptr;
   if constexpr (DBG == 3) {
     trc = a.trace + (size_t)blockIdx.x * 48;
@@ -79,8 +93,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs), "s"(a.row_mean));
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
-  if (NT == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
-    f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
+  if (NC == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+    if (tid < 256) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
     return;
   }
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
@@ -119,14 +133,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   const bf16* w_src[W_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
-    const int i = tid + NT * j;
+    const int i = (stid & (NT - 1)) + NT * j;
     const int row = i / CPR, c = (i % CPR) ^ swz(row);
     const int gr = min(m0 + row, a.M - 1);
     a_src[j] = a.A + (size_t)gr * a.lda + c * 8;
   }
 #pragma unroll
   for (int j = 0; j < W_IT; ++j) {
-    const int i = tid + NT * j;
+    const int i = (stid & (NT - 1)) + NT * j;
     const int row = i / CPR, c = (i % CPR) ^ swz(row);
     const int gr = min(n0 + row, a.N - 1);
     w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
@@ -136,9 +150,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   auto stage = [&](int buf, int kt) {
     char* base = ring + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (swave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (wave * 64 + NT * j) * 16);
+    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (swave * 64 + NT * j) * 16);
   };
 
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
@@ -154,9 +168,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
   static_assert(NSTAGE >= 2 && NSTAGE <= 8 && (NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+  static_assert((NT & (NT - 1)) == 0, "staging thread count must be a power of two");
+  if (NLOAD == 0 || is_loader) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < KT) stage(s, s);
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < KT) stage(s, s);
+  }
+  if constexpr (NLOAD > 0) {
+    if (is_loader) {
+      // ---- loader waves: wait for tile kt, meet the consumers at the barrier that hands it over (and tells us they are done
+      // reading tile kt - 1), refill that buffer with tile kt + NSTAGE - 1.  Same RAW / WAR argument as the classic ring.
+      int nbuf_l = NSTAGE - 1;
+      if constexpr (DBG == 3) { if (stid == 0) trc[47] = __builtin_amdgcn_s_memtime(); }
+      for (int kt = 0; kt < KT; ++kt) {
+        const int rem = KT - 1 - kt;
+        wait_stages<LPT, 0>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < KT) stage(nbuf_l, kt + NSTAGE - 1);
+        nbuf_l = (nbuf_l + 1 == NSTAGE) ? 0 : nbuf_l + 1;
+      }
+      if (FUSE == 1) __syncthreads();                 // the consumers' epilogue barriers (every wave of the workgroup)
+      if (FUSE == 2) __builtin_amdgcn_s_barrier();
+      return;
+    }
+  }
   // Epilogue operands are fetched right after the first stages were issued and stay in flight under the first
   // NSTAGE - 1 K-steps: vmcnt retires in order, so the waits for tiles 0 .. NSTAGE-2 (older than these loads) allow
   // NPC more outstanding operations.  NPC counts only loads that are certainly issued: unconditional (clamped
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   constexpr bool PREF = (TM * TN <= 4);
   static_assert(FUSE == 0 || (PREF && BM == 64 && BN == 64 && WGM == 2 && WGN == 2), "fused AdaLN: 64x64 tiles only");
   static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
-  constexpr int NPC = FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0));
+  constexpr int NPC = NLOAD ? 0 : (FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0)));
   static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
   f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
   f32x4 pf_c[FUSE == 1 ? TN : 1], pf_d[FUSE == 1 ? TN : 1];
@@ -180,66 +215,123 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs a) {
   int pf_len[PREF ? TM : 1];
   float pf_rm[FUSE == 2 ? TM : 1];   // producer: the rows' centring offsets (row means as of the previous norm)
   auto ldv4 = [](const float* ptr) -> f32x4 { return *(const f32x4*)ptr; };
-  if (PREF) {
-    if (EPI == EPI_GATE_RES) {
-      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm0 + j * 16 + fr, mc = min(m, a.M - 1);
-        const int seq = div_magic(mc, a.rows_per_seq, a.rps_magic);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
-          const size_t goff = eoff + (a.gate_rows == 1 ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
-          pf_gate[i][j] = ldv4(a.gate + goff);                       // counted
-          pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);      // counted
-          if (FUSE == 2) pf_ns[i][j] = ldv4(a.next_scale + goff);    // counted
+  // Classic launch: right here, behind the prologue's stages (see above).  Role split: the consumers issue no DMA, and asking
+  // for these at kernel entry would put their ~10 loads per lane on the address path IN FRONT of the loaders' first tiles
+  // (measured: first tile landed 640 cycles later) -- they go out behind the first hand-over barrier instead.
+  auto fetch_epilogue_operands = [&]() {
+    if (PREF) {
+      if (EPI == EPI_GATE_RES) {
+        const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
+  #pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int m = m0 + wm0 + j * 16 + fr, mc = min(m, a.M - 1);
+          const int seq = div_magic(mc, a.rows_per_seq, a.rps_magic);
+  #pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
+            const size_t goff = eoff + (a.gate_rows == 1 ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
+            pf_gate[i][j] = ldv4(a.gate + goff);                       // counted
+            pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);      // counted
+            if (FUSE == 2) pf_ns[i][j] = ldv4(a.next_scale + goff);    // counted
+          }
         }
       }
     }
-  }
-  if (FUSE == 1) {
-    // As few vector-memory instructions as possible: the CU's address unit takes ~16 cycles per wave-instruction whatever
-    // its width, and all 12 waves of a CU run this block at once (tools/gemm_trace.hip: 16 extra loads per wave cost 2100
-    // cycles before the first K-step).  One table row per evaluation (cd_rows == 1, checked on the host): c and d do not
-    // depend on the row -> 2 TN loads; statistics: 4 threads per row, ln_parts / 4 <= 4 consecutive (mean, M2) pairs each
-    // (the 64 lanes of a wave read one contiguous range of [M][parts][2]); entries past a thread's share repeat its last.
-    const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
-    const float* cbase = a.ln_c + eoff;
-    const float* dbase = a.ln_d + eoff;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const unsigned nc = (unsigned)min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
-      pf_c[i] = ldv4(cbase + nc);                                    // counted
-      pf_d[i] = ldv4(dbase + nc);                                    // counted
-    }
-    const int pp = a.ln_parts >> 2;
-    const float* sbase = a.ln_stats + (size_t)m0 * a.ln_parts * 2;          // uniform
-    const unsigned rel_max = (unsigned)((a.M - m0) * a.ln_parts - 1);       // last valid pair of the tile's rows
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned rel = min((unsigned)(tid * pp + min(u, pp - 1)), rel_max);
-      pf_st[u] = *(const f32x2*)(sbase + rel * 2u);                  // counted
-    }
-  }
-  if (PREF) {  // not counted: may be skipped
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = n0 + wn0 + i * 16 + fq * 4;
-      pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (EPI == EPI_GATE_RES) {  // only fetched here; compared in the epilogue (a use now would drain vmcnt)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
-        pf_len[j] = a.seq_len ? a.seq_len[div_magic(mc, a.rows_per_seq, a.rps_magic)] : a.rows_per_seq;
-        if (FUSE == 2) pf_rm[j] = a.row_mean[mc];
+    if (FUSE == 1) {
+      // As few vector-memory instructions as possible: the CU's address unit takes ~16 cycles per wave-instruction whatever
+      // its width, and all 12 waves of a CU run this block at once (tools/gemm_trace.hip: 16 extra loads per wave cost 2100
+      // cycles before the first K-step).  One table row per evaluation (cd_rows == 1, checked on the host): c and d do not
+      // depend on the row -> 2 TN loads; statistics: 4 threads per row, ln_parts / 4 <= 4 consecutive (mean, M2) pairs each
+      // (the 64 lanes of a wave read one contiguous range of [M][parts][2]); entries past a thread's share repeat its last.
+      const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
+      const float* cbase = a.ln_c + eoff;
+      const float* dbase = a.ln_d + eoff;
+  #pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const unsigned nc = (unsigned)min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
+        pf_c[i] = ldv4(cbase + nc);                                    // counted
+        pf_d[i] = ldv4(dbase + nc);                                    // counted
+      }
+      const int pp = a.ln_parts >> 2;
+      const float* sbase = a.ln_stats + (size_t)m0 * a.ln_parts * 2;          // uniform
+      const unsigned rel_max = (unsigned)((a.M - m0) * a.ln_parts - 1);       // last valid pair of the tile's rows
+  #pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned rel = min((unsigned)(tid * pp + min(u, pp - 1)), rel_max);
+        pf_st[u] = *(const f32x2*)(sbase + rel * 2u);                  // counted
       }
     }
-  }
+    if (PREF) {  // not counted: may be skipped
+  #pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn0 + i * 16 + fq * 4;
+        pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (EPI == EPI_GATE_RES) {  // only fetched here; compared in the epilogue (a use now would drain vmcnt)
+  #pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
+          pf_len[j] = a.seq_len ? a.seq_len[div_magic(mc, a.rows_per_seq, a.rps_magic)] : a.rows_per_seq;
+          if (FUSE == 2) pf_rm[j] = a.row_mean[mc];
+        }
+      }
+    }
+  };
+  if (NLOAD == 0) fetch_epilogue_operands();
 
   int buf = 0, nbuf = NSTAGE - 1;
   if constexpr (DBG == 3) { if (tid == 0) trc[2] = __builtin_amdgcn_s_memtime(); }
+  if constexpr (NLOAD > 0) {
+    // ---- consumer waves of a role-split launch.  Step kt: pass the barrier that hands tile kt over, issue its fragment
+    // reads into one register set, run the MFMAs of tile kt - 1 from the other set under those reads, and retire the reads
+    // (lgkmcnt(0)) BEFORE the next barrier -- behind it the loader refills the buffer just read.
+    bf16x8 xs2[2][BK / 32][TM], ws2[2][BK / 32][TN];
+    auto reads = [&](auto pc, int b) {
+      constexpr int P = decltype(pc)::value;
+      const char* As = ring + b * STAGE;
+      const char* Ws = As + A_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        const int c = kk * 4 + fq;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int row = wm0 + j * 16 + fr;
+          xs2[P][kk][j] = *(const bf16x8*)(As + row * ROWB + ((c ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int row = wn0 + i * 16 + fr;
+          ws2[P][kk][i] = *(const bf16x8*)(Ws + row * ROWB + ((c ^ swz(row)) << 4));
+        }
+      }
+    };
+    auto mfmas = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[P][kk][i], xs2[P][kk][j], acc[i][j], 0, 0, 0);
+    };
+    auto body = [&](auto pc, int kt) {
+      constexpr int P = decltype(pc)::value;
+      __builtin_amdgcn_s_barrier();
+      if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
+      reads(pc, buf);
+      if (kt > 0) mfmas(std::integral_constant<int, 1 - P>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+      body(std::integral_constant<int, 0>{}, kt);
+      if (kt == 0) fetch_epilogue_operands();
+      if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if ((KT - 1) & 1) mfmas(std::integral_constant<int, 1>{});
+    else mfmas(std::integral_constant<int, 0>{});
+  } else
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = KT - 1 - kt;  // stages issued after tile kt
     // tile kt must have landed; the min(NSTAGE - 2, rem) younger stages may stay in flight, and so may the NPC
@@ -532,7 +624,7 @@ inline int pick_group_shift(int tiles_m, int tiles_n, int bm, int bn) {
   return best_s;
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -553,8 +645,8 @@ int launch(GemmArgs& a, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE>), dim3(grid), dim3(64 * WGM * WGN), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -562,6 +654,13 @@ int launch(GemmArgs& a, hipStream_t st) {
 // tile_hint: 0 = auto; 1 = 128x128 (8 waves, 2 stages), 2 = 128x64 (3 stages), 3 = 64x64 (3 stages; 4 for a one-round grid
 // with K >= 2048), 9 = the 256x256 ping-pong kernel of gemm_bf16_pp.hip (what auto picks at large M).  One code path per
 // tile family: the tuning variants that were measured and lost (deeper rings, other wave grids, split-K) are in DESIGN 4.
+inline bool role_split_on() {
+#ifdef F5E_TOOLS
+  if (const char* f = getenv("F5E_GEMM_ROLE")) return atoi(f) != 0;   // diagnostics build only: A/B against the classic ring
+#endif
+  return true;
+}
+
 template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
@@ -572,6 +671,9 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
     F5E_REQUIRE(!(EPI == EPI_QKV_ROPE && a.qn_w), "gemm_bf16: fused AdaLN and qk_norm need different tiles");
     if constexpr (EPI == EPI_GATE_RES) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
+      // one-round grids (out-projection / FF2 at batch 1: 240 workgroups on 256 CUs): role split, 4 loader + 4 consumer
+      // waves, 4-stage ring -- see the NLOAD note at the kernel
+      if (role_split_on() && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4>(a, st);
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
@@ -596,6 +698,9 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   // HBM): a 4th stage hides the HBM latency (15.5 -> 12.9 us at M = 938); at K = 1024 or 3 workgroups per CU it does not.
   if (sel == 1) return launch<128, 128, EPI, 2, 4, 2>(a, st);
   if (sel == 2) return launch<128, 64, EPI, 3>(a, st);
+  if constexpr (EPI == EPI_GATE_RES) {
+    if (role_split_on() && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 0, 4>(a, st);
+  }
   if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4>(a, st);
   return launch<64, 64, EPI, 3>(a, st);
 }

@@ -82,7 +82,45 @@ def min_loads(ins, start, stop):
 
 bad = 0
 for key, ins in sorted(body.items()):
-    BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE = key[:8]   # a 9th parameter (K-step) does not change the counted loads
+    BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE = key[:8]
+    NLOAD = key[8] if len(key) > 8 else 0
+    if NLOAD:
+        # Role split: only the loader waves stage and count vmcnt, and their waits allow NO other outstanding operation, so
+        # their code -- from the prologue's first LDS-DMA to their s_endpgm, a contiguous run the consumers never enter --
+        # must hold nothing but LDS-DMAs on the vector-memory queue.
+        # the loader's prologue = the first run of back-to-back LDS-DMAs (the prefetch-only workgroups' DMAs sit one per
+        # exec-masked branch); everything reachable from there, along both arms of every branch, is loader code
+        first = next((i for i, t in enumerate(ins) if t.startswith("global_load_lds")
+                      and sum(x.startswith("global_load_lds") for x in ins[i + 1:i + 8]) >= 1), None)
+        okr, msg = False, "no loader prologue found"
+        if first is not None:
+            label_at = {m.group(1): i for i, t in enumerate(ins) for m in [LABEL.match(t)] if m}
+            seen, work = set(), [first]
+            while work:
+                i = work.pop()
+                while i < len(ins) and i not in seen:
+                    seen.add(i)
+                    t = ins[i]
+                    m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", t)
+                    if m:
+                        work.append(label_at[m.group(1)])
+                    m = re.match(r"s_branch (\.LBB\d+_\d+)", t)
+                    if m:
+                        i = label_at[m.group(1)]
+                        continue
+                    if t.startswith("s_endpgm"):
+                        break
+                    i += 1
+            run = [ins[i] for i in sorted(seen)]
+            other = [t for t in run if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", t)
+                     and not t.startswith("global_load_lds")]
+            ndma = sum(t.startswith("global_load_lds") for t in run)
+            nbar = sum(t.startswith("s_barrier") for t in run)
+            okr = not other and nbar >= 1 and any(t.startswith("s_endpgm") for t in run)
+            msg = f"loader code = {len(run)} instructions: {ndma} LDS-DMAs, {nbar} barrier(s), {len(other)} other vector-memory operations"
+        bad += not okr
+        print(f"{'ok  ' if okr else 'FAIL'} gemm_bf16_kernel<{','.join(map(str, key))}> (role split): {msg}")
+        continue
     TM, TN = BM // WGM // 16, BN // WGN // 16
     pref = TM * TN <= 4
     npc = 2 * TN + 4 if FUSE == 1 else 3 * TM * TN if FUSE == 2 else (2 * TM * TN if (pref and EPI == 2) else 0)

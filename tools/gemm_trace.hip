@@ -29,6 +29,34 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
     case 6: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 4, 3>(a, st);   // 8 waves (2 x 4), 4-stage ring
     case 7: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 4, 3>(a, st);   // 8 waves, 3-stage ring
     case 8: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 4, 2, 3>(a, st);   // 8 waves (4 x 2), 4-stage ring
+    // role split (NLOAD loader waves + 4 consumer waves): template order BM, BN, EPI, NSTAGE, WGM, WGN, DBG, FUSE, NLOAD
+    case 30: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 2, 3, 0, 1>(a, st);
+    case 31: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 2, 3, 0, 2>(a, st);
+    case 32: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3, 0, 1>(a, st);
+    case 33: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3, 0, 2>(a, st);
+    case 34: *bm = 64; *bn = 64; return launch<64, 64, EPI, 5, 2, 2, 3, 0, 1>(a, st);
+    case 35: *bm = 128; *bn = 64; return launch<128, 64, EPI, 3, 2, 2, 3, 0, 2>(a, st);
+    case 36: *bm = 128; *bn = 128; return launch<128, 128, EPI, 3, 4, 2, 3, 0, 2>(a, st);
+    case 37: *bm = 128; *bn = 128; return launch<128, 128, EPI, 3, 2, 2, 3, 0, 2>(a, st);   // 4 consumers, 64 x 64 each
+    case 38: *bm = 64; *bn = 64; return launch<64, 64, EPI, 3, 2, 2, 3, 0, 4>(a, st);      // 4 loaders + 4 consumers
+    case 39: *bm = 64; *bn = 64; return launch<64, 64, EPI, 4, 2, 2, 3, 0, 4>(a, st);
+    case 50: *bm = 128; *bn = 128; return launch<128, 128, EPI, 3, 4, 2, 3, 0, 4>(a, st);  // 8 consumers (32 x 64 each)
+    case 51: *bm = 128; *bn = 64; return launch<128, 64, EPI, 3, 2, 2, 3, 0, 4>(a, st);    // 4 consumers (64 x 32 each)
+    case 52: *bm = 64; *bn = 128; return launch<64, 128, EPI, 3, 2, 2, 3, 0, 4>(a, st);    // 4 consumers (32 x 64 each)
+    case 53: *bm = 128; *bn = 128; return launch<128, 128, EPI, 3, 2, 2, 3, 0, 4>(a, st);  // 4 consumers (64 x 64 each)
+    case 54: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 2, 2, 3, 0, 4>(a, st);
+    case 42:  // fused AdaLN, 4 loaders, 4 stages (what the dispatcher launches for the one-round producers)
+      *bm = 64; *bn = 64;
+      if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 4, 2, 2, 3, 2, 4>(a, st);
+      else return launch<64, 64, EPI, 4, 2, 2, 3, 1, 4>(a, st);
+    case 41:  // fused AdaLN, 4 loaders
+      *bm = 64; *bn = 64;
+      if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 3, 2, 2, 3, 2, 4>(a, st);
+      else return launch<64, 64, EPI, 3, 2, 2, 3, 1, 4>(a, st);
+    case 40:  // fused AdaLN, role split
+      *bm = 64; *bn = 64;
+      if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 3, 2, 2, 3, 2, 1>(a, st);
+      else return launch<64, 64, EPI, 3, 2, 2, 3, 1, 1>(a, st);
     case 10:  // fused AdaLN: consumer for the bf16 / gelu epilogues, producer for gate + residual
       *bm = 64; *bn = 64;
       if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 3, 2, 2, 3, 2>(a, st);
@@ -59,7 +87,9 @@ int main(int argc, char** argv) {
   hipMalloc(&gate, N * 4);
   hipMalloc(&resid, (size_t)M * N * 4);
   hipMalloc(&trace, (size_t)L * max_grid * 48 * 8);
-  float *stats, *cd;
+  float *stats, *cd, *row_mean;
+  hipMalloc(&row_mean, (size_t)M * 4);
+  hipMemset(row_mean, 0, (size_t)M * 4);
   hipMalloc(&stats, (size_t)M * 32 * 2 * 4);
   hipMalloc(&cd, (size_t)2 * N * 4);
   hipMemset(stats, 0, (size_t)M * 32 * 2 * 4);
@@ -93,7 +123,8 @@ int main(int argc, char** argv) {
     a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = rps;
     if (epi == 3) { a.q = qb; a.k = kb; a.vt = vtb; a.n_pad = n_pad; a.heads = heads; a.rope_heads = heads; a.cos_sin = cs; }
     a.trace = trace + (size_t)l * max_grid * 48;
-    if (variant == 10) {
+    if (variant == 10 || (variant >= 40 && variant <= 42)) {
+      a.row_mean = row_mean;
       if (epi == 2) { a.xs_out = out; a.ld_xs = N; a.next_scale = gate; a.stats_out = stats; }
       else { a.ln_stats = stats; a.ln_parts = K / 64; a.ln_c = cd; a.ln_d = cd + N; a.cd_stride = 2 * N; a.cd_rows = 1;
              a.ln_eps = 1e-6f; a.bias = nullptr; }
@@ -143,6 +174,15 @@ int main(int argc, char** argv) {
          med(gap), med(ramp), med(span));
   printf("  per workgroup [cycles, median]: entry->prologue DMAs issued %.0f | +prefetch issued %.0f | entry->tile0 landed %.0f | K-loop iteration %.0f (x%d) | loop %.0f | epilogue %.0f | total %.0f (= %.2f us)\n",
          med(dmaissue), med(issue), med(first), med(iter), KT, med(loop), med(epil), med(wg_total), med(wg_total) / mhz);
+  if (variant >= 30) {  // role split: when the loader's prologue DMAs were all issued (slot 47, loader thread 0)
+    std::vector<double> li;
+    for (int l = 12; l < L; ++l)
+      for (int w = 0; w < grid; ++w) {
+        const unsigned long long* t = &h[((size_t)l * max_grid + w) * 48];
+        li.push_back((double)(t[47] - t[1]));
+      }
+    printf("  loader: entry -> prologue DMAs issued %.0f cycles\n", med(li));
+  }
   {  // per-K-step profile (median over workgroups of the last launch): cycles from step kt's barrier to step kt+1's
     const int l = L - 1, nk = std::min(KT, 36);
     printf("  K-step profile [cycles]:");
@@ -156,7 +196,7 @@ int main(int argc, char** argv) {
     }
     printf("\n");
   }
-  if (variant == 10) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
+  if (variant == 10 || (variant >= 40 && variant <= 42)) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
     std::vector<double> a42, a43, a44, a45, a40;
     const int l = L - 1;
     for (int w = 0; w < grid; ++w) {
