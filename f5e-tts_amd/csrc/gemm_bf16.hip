@@ -54,7 +54,17 @@ __device__ __forceinline__ void wait_stages(int nst) {
 // ~18 cycles per 1 KiB LDS-DMA instruction (tools/l2_probe.hip: 57 B/clk per CU from L2, whatever the number of waves), so a
 // 64 x 64 K-step carries 288 cycles of DMA issue against 128 of MFMA -- and with every wave doing both, behind one barrier,
 // the two ADD (553 cycles per step measured).  Split, the loader's issue runs beside the consumers' reads and MFMAs.
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0>
+// DSTEP (role split only): K-tiles per hand-over barrier.  A barrier is a full rendezvous of loaders and consumers and costs
+// ~100 cycles of skew per K-step on top of max(loader issue, consumer reads + MFMAs); handing over TWO tiles per barrier
+// halves that (K % 128 == 0; ring of NSTAGE >= 3 DSTEP tiles: DSTEP being read, DSTEP landed or landing, DSTEP being issued).
+// FETCH (role split only): where the consumers request the epilogue operands (x tile, gate, statistics: ~14 loads per lane,
+// ~1000 cycles of the address path per workgroup, latency of a cold line from the Infinity Cache or HBM).
+//   0: behind the first hand-over barrier (they stall that K-step's issue);  1: behind an extra barrier that the loaders join
+//   once their prologue DMAs are issued -- the address path idles from there until the first tile lands.
+// (At kernel entry they delay the first tile by ~640 cycles.  Over the LAST K-tiles, where the loaders fall silent, they come
+// back too late in the block chain: measured slower in situ, 42.3 vs 40.1 ms per C2 pass.)
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0, int DSTEP = 1,
+          int FETCH = 0>
 __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   if (FUSE == 2) asm volatile("" ::"s"(a.next_scale), "s"(a.xs_out), "s"(a.stats_out), "s"(a.ld_xs), "s"(a.row_mean));
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
-  if (NC == 256 && (int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+  if ((int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h), 256 threads of them
     if (tid < 256) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
     return;
   }
@@ -167,25 +177,35 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   // NSTAGE-deep LDS ring fed by LDS-DMA: NSTAGE-1 K-tiles are in flight while one is consumed.  Counted vmcnt +
   // raw s_barrier (a __syncthreads() would drain the DMA queue: cdna guide "Pipelining across barriers").
   constexpr int LPT = A_IT + W_IT;  // LDS-DMA instructions per thread per stage
-  static_assert(NSTAGE >= 2 && NSTAGE <= 8 && (NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 8 && (DSTEP > 1 || (NSTAGE - 2) * LPT <= 63), "vmcnt is a 6-bit counter");
   static_assert((NT & (NT - 1)) == 0, "staging thread count must be a power of two");
+  static_assert(DSTEP == 1 || (NLOAD > 0 && DSTEP == 2 && NSTAGE >= 3 * DSTEP), "DSTEP: role split, ring of >= 3 steps");
+  constexpr int NPRO = NSTAGE - DSTEP;      // tiles issued ahead of the first hand-over (DSTEP == 1: the classic NSTAGE - 1)
+  static_assert((NSTAGE - 2 * DSTEP) * LPT <= 63, "vmcnt is a 6-bit counter");
   if (NLOAD == 0 || is_loader) {
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
+    for (int s = 0; s < NPRO; ++s)
       if (s < KT) stage(s, s);
   }
   if constexpr (NLOAD > 0) {
     if (is_loader) {
-      // ---- loader waves: wait for tile kt, meet the consumers at the barrier that hands it over (and tells us they are done
-      // reading tile kt - 1), refill that buffer with tile kt + NSTAGE - 1.  Same RAW / WAR argument as the classic ring.
-      int nbuf_l = NSTAGE - 1;
+      // ---- loader waves: wait for tiles kt .. kt + DSTEP - 1, meet the consumers at the barrier that hands them over (and
+      // tells us they are done reading the DSTEP tiles before), refill those buffers with tiles kt + NPRO ...  Same RAW / WAR
+      // argument as the classic ring, per step of DSTEP tiles.
+      int nbuf_l = NPRO % NSTAGE;
       if constexpr (DBG == 3) { if (stid == 0) trc[47] = __builtin_amdgcn_s_memtime(); }
-      for (int kt = 0; kt < KT; ++kt) {
-        const int rem = KT - 1 - kt;
-        wait_stages<LPT, 0>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      if (FETCH == 1) __builtin_amdgcn_s_barrier();   // prologue issued: the consumers may use the address path now
+      for (int kt = 0; kt < KT; kt += DSTEP) {
+        // issued so far: tiles [0, min(KT, kt + NPRO)); all but the ones younger than this step's tiles must have landed:
+        // min(tiles behind this step, NSTAGE - 2 DSTEP) may stay in flight
+        const int rem = KT - DSTEP - kt;             // tiles behind this step's (K % (64 DSTEP) == 0: host check)
+        wait_stages<LPT, 0>(rem < NSTAGE - 2 * DSTEP ? (rem < 0 ? 0 : rem) : NSTAGE - 2 * DSTEP);
         __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < KT) stage(nbuf_l, kt + NSTAGE - 1);
-        nbuf_l = (nbuf_l + 1 == NSTAGE) ? 0 : nbuf_l + 1;
+#pragma unroll
+        for (int d = 0; d < DSTEP; ++d) {
+          if (kt + NPRO + d < KT) stage(nbuf_l, kt + NPRO + d);
+          nbuf_l = (nbuf_l + 1 == NSTAGE) ? 0 : nbuf_l + 1;
+        }
       }
       if (FUSE == 1) __syncthreads();                 // the consumers' epilogue barriers (every wave of the workgroup)
       if (FUSE == 2) __builtin_amdgcn_s_barrier();
@@ -203,7 +223,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   asm volatile("" ::: "memory");
   if constexpr (DBG == 3) { if (tid == 0) trc[46] = __builtin_amdgcn_s_memtime(); }
   constexpr bool PREF = (TM * TN <= 4);
-  static_assert(FUSE == 0 || (PREF && BM == 64 && BN == 64 && WGM == 2 && WGN == 2), "fused AdaLN: 64x64 tiles only");
+  // fused AdaLN: 64-row tiles of 32 x 32 wave sub-tiles (row statistics: 4 threads per row = the first 256 threads); the
+  // producer is 64 x 64, a role-split consumer may be wider (64 x 128 / 64 x 192: the A panel is staged once per K-step)
+  static_assert(FUSE == 0 || (PREF && BM == 64 && WGM == 2 && BN == 32 * WGN && (BN == 64 || (FUSE == 1 && NLOAD > 0))),
+                "fused AdaLN: 64-row tiles, 32 x 32 wave sub-tiles");
   static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
   constexpr int NPC = NLOAD ? 0 : (FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0)));
   static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
@@ -217,16 +240,16 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   auto ldv4 = [](const float* ptr) -> f32x4 { return *(const f32x4*)ptr; };
   // Classic launch: right here, behind the prologue's stages (see above).  Role split: the consumers issue no DMA, and asking
   // for these at kernel entry would put their ~10 loads per lane on the address path IN FRONT of the loaders' first tiles
-  // (measured: first tile landed 640 cycles later) -- they go out behind the first hand-over barrier instead.
+  // (measured: first tile landed 640 cycles later) -- they go out late in the K loop instead (see the consumer loop).
   auto fetch_epilogue_operands = [&]() {
     if (PREF) {
       if (EPI == EPI_GATE_RES) {
         const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.eval_stride : 0;
-  #pragma unroll
+#pragma unroll
         for (int j = 0; j < TM; ++j) {
           const int m = m0 + wm0 + j * 16 + fr, mc = min(m, a.M - 1);
           const int seq = div_magic(mc, a.rows_per_seq, a.rps_magic);
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < TN; ++i) {
             const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
             const size_t goff = eoff + (a.gate_rows == 1 ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       const size_t eoff = a.eval_ptr ? (size_t)load_uniform_i32(a.eval_ptr) * a.cd_eval_stride : 0;
       const float* cbase = a.ln_c + eoff;
       const float* dbase = a.ln_d + eoff;
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < TN; ++i) {
         const unsigned nc = (unsigned)min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
         pf_c[i] = ldv4(cbase + nc);                                    // counted
@@ -255,20 +278,20 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       const int pp = a.ln_parts >> 2;
       const float* sbase = a.ln_stats + (size_t)m0 * a.ln_parts * 2;          // uniform
       const unsigned rel_max = (unsigned)((a.M - m0) * a.ln_parts - 1);       // last valid pair of the tile's rows
-  #pragma unroll
+#pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned rel = min((unsigned)(tid * pp + min(u, pp - 1)), rel_max);
-        pf_st[u] = *(const f32x2*)(sbase + rel * 2u);                  // counted
+        const unsigned rel = min((unsigned)((tid & 255) * pp + min(u, pp - 1)), rel_max);
+        if (NC == 256 || tid < 256) pf_st[u] = *(const f32x2*)(sbase + rel * 2u);   // counted (classic: every thread)
       }
     }
     if (PREF) {  // not counted: may be skipped
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int n = n0 + wn0 + i * 16 + fq * 4;
         pf_bias[i] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (EPI == EPI_GATE_RES) {  // only fetched here; compared in the epilogue (a use now would drain vmcnt)
-  #pragma unroll
+#pragma unroll
         for (int j = 0; j < TM; ++j) {
           const int mc = min(m0 + wm0 + j * 16 + fr, a.M - 1);
           pf_len[j] = a.seq_len ? a.seq_len[div_magic(mc, a.rows_per_seq, a.rps_magic)] : a.rows_per_seq;
@@ -317,16 +340,21 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
     };
     auto body = [&](auto pc, int kt) {
       constexpr int P = decltype(pc)::value;
-      __builtin_amdgcn_s_barrier();
+      // DSTEP == 2: KT is even (host check), so tile parity P == position inside the step
+      if (DSTEP == 1 || P == 0) __builtin_amdgcn_s_barrier();
       if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
       reads(pc, buf);
       if (kt > 0) mfmas(std::integral_constant<int, 1 - P>{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (DSTEP == 1 || P == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next hand-over
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     };
+    if (FETCH == 1) {
+      __builtin_amdgcn_s_barrier();                    // the loaders' prologue DMAs are issued (see FETCH)
+      fetch_epilogue_operands();
+    }
     for (int kt = 0; kt < KT; kt += 2) {
       body(std::integral_constant<int, 0>{}, kt);
-      if (kt == 0) fetch_epilogue_operands();
+      if (FETCH == 0 && kt == 0) fetch_epilogue_operands();
       if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
     }
     if ((KT - 1) & 1) mfmas(std::integral_constant<int, 1>{});
@@ -400,7 +428,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
         m2 += pf_st[u][1] + cols * dm * dm;
       }
     m2 = add_xor2(add_xor1(m2));
-    if (sq == 0) {
+    if (sq == 0 && (NC == 256 || tid < 256)) {
       fuse_lds[(tid >> 2) * 2] = mean;     // relative to the offset the row's xs was centred with (row_mean)
       fuse_lds[(tid >> 2) * 2 + 1] = rsqrtf(m2 / (float)a.K + a.ln_eps);
       // the producer behind this consumer centres with the row's CURRENT mean: one workgroup per row tile moves it along
@@ -624,7 +652,8 @@ inline int pick_group_shift(int tiles_m, int tiles_n, int bm, int bn) {
   return best_s;
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1,
+          int FETCH = 0>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -640,13 +669,13 @@ int launch(GemmArgs& a, hipStream_t st) {
   a.rps_magic = div_magic_of(a.rows_per_seq);
   a.n_main = a.tiles_m * a.tiles_n;
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
-  const int grid = a.n_main + ((WGM * WGN == 4 && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
+  const int grid = a.n_main + (((WGM * WGN == 4 || NLOAD > 0) && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
   if (grid == a.n_main) a.pf = F5ePrefetch{};
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, FETCH>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, FETCH>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -659,6 +688,13 @@ inline bool role_split_on() {
   if (const char* f = getenv("F5E_GEMM_ROLE")) return atoi(f) != 0;   // diagnostics build only: A/B against the classic ring
 #endif
   return true;
+}
+// diagnostics build only: F5E_GEMM_VAR = 10 * dstep_variant + fetch_variant picks among the role-split instantiations
+inline int role_var() {
+#ifdef F5E_TOOLS
+  if (const char* f = getenv("F5E_GEMM_VAR")) return atoi(f);
+#endif
+  return -1;
 }
 
 template <int EPI>
@@ -673,11 +709,55 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
       // one-round grids (out-projection / FF2 at batch 1: 240 workgroups on 256 CUs): role split, 4 loader + 4 consumer
       // waves, 4-stage ring -- see the NLOAD note at the kernel
-      if (role_split_on() && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4>(a, st);
+      if (role_split_on() && blocks(64, 64) <= 256) {
+#ifdef F5E_TOOLS
+        switch (role_var()) {
+          case 0: return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 0>(a, st);
+          case 1: return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 1>(a, st);
+          case 10: if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 0>(a, st); break;
+          case 11: if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 1>(a, st); break;
+          case 20: if (a.K % 128 == 0) return launch<64, 64, EPI, 8, 2, 2, 0, 2, 4, 2, 0>(a, st); break;
+          case 30: return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 1, 0>(a, st);
+        }
+#endif
+        // two K-tiles per hand-over barrier on a ring of six (in situ at C2, ms per pass: classic ring 41.4; 4 stages, one tile
+        // per barrier 40.9; this 40.7; 8-tile ring 41.2; 6 stages, one tile per barrier 41.8)
+        if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 0>(a, st);
+        return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 0>(a, st);
+      }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
       F5E_REQUIRE(a.ln_stats && !a.stats_out, "gemm_bf16: this epilogue can only consume AdaLN statistics");
+      // one-round grids of WIDE tiles (batch 1: QKV 15 x 16 tiles of 64 x 192, FF1 15 x 16 of 64 x 128 on 256 CUs): role
+      // split, 4 loader waves + 12 / 8 consumer waves of 32 x 32 sub-tiles; the A panel is staged once per K-step for 3 / 2
+      // classic tiles' worth of columns, which is what the address path -- the bound resource -- is spared
+      if (role_split_on()) {
+        int wide = 3;
+#ifdef F5E_TOOLS
+        if (const char* f = getenv("F5E_GEMM_WIDE")) wide = atoi(f);   // diagnostics build only: bit 0 QKV, bit 1 the others
+#endif
+        if constexpr (EPI == EPI_QKV_ROPE) {
+          if ((wide & 1) && a.N % 192 == 0 && blocks(64, 192) <= 256) {
+#ifdef F5E_TOOLS
+            if (role_var() % 10 == 1) return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1, 1>(a, st);
+#endif
+            return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1, 0>(a, st);
+          }
+        } else {
+          if ((wide & 2) && a.N % 128 == 0 && blocks(64, 128) <= 256) {
+#ifdef F5E_TOOLS
+            switch (role_var()) {
+              case 1: return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 1>(a, st);
+              case 10: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st); break;
+              case 11: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 1>(a, st); break;
+            }
+#endif
+            if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st);
+            return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 0>(a, st);
+          }
+        }
+      }
       return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
     }
   }

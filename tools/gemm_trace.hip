@@ -45,6 +45,37 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
     case 52: *bm = 64; *bn = 128; return launch<64, 128, EPI, 3, 2, 2, 3, 0, 4>(a, st);    // 4 consumers (32 x 64 each)
     case 53: *bm = 128; *bn = 128; return launch<128, 128, EPI, 3, 2, 2, 3, 0, 4>(a, st);  // 4 consumers (64 x 64 each)
     case 54: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 2, 2, 3, 0, 4>(a, st);
+    // 8 consumer waves (32 x 32 sub-tiles, the per-wave epilogue work of the classic 64 x 64 tile) + 4 loaders on bigger tiles
+    case 60: *bm = 128; *bn = 64; return launch<128, 64, EPI, 3, 4, 2, 3, 0, 4>(a, st);
+    case 61: *bm = 64; *bn = 128; return launch<64, 128, EPI, 3, 2, 4, 3, 0, 4>(a, st);
+    case 62: *bm = 128; *bn = 64; return launch<128, 64, EPI, 4, 4, 2, 3, 0, 4>(a, st);
+    case 63: *bm = 96; *bn = 128; return launch<96, 128, EPI, 3, 2, 4, 3, 0, 4>(a, st);    // 48 x 32 sub-tiles
+    case 65: *bm = 96; *bn = 128; return launch<96, 128, EPI, 4, 2, 4, 3, 0, 4>(a, st);
+    case 70: *bm = 64; *bn = 192; return launch<64, 192, EPI, 3, 2, 6, 3, 0, 4>(a, st);   // 12 consumers + 4 loaders
+    case 71: *bm = 64; *bn = 192; return launch<64, 192, EPI, 4, 2, 6, 3, 0, 4>(a, st);
+    case 72: *bm = 64; *bn = 128; return launch<64, 128, EPI, 4, 2, 4, 3, 0, 4>(a, st);   // 8 consumers + 4 loaders, 4 stages
+    case 73:  // fused AdaLN consumers on the wide role-split tiles (bf16 / gelu / qkv epilogues only)
+      if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 192; return launch<64, 192, EPI, 3, 2, 6, 3, 1, 4>(a, st); }
+      return -1;
+    case 74:
+      if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 192; return launch<64, 192, EPI, 4, 2, 6, 3, 1, 4>(a, st); }
+      return -1;
+    case 75:
+      if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 128; return launch<64, 128, EPI, 3, 2, 4, 3, 1, 4>(a, st); }
+      return -1;
+    case 76:
+      if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 128; return launch<64, 128, EPI, 4, 2, 4, 3, 1, 4>(a, st); }
+      return -1;
+    // two tiles per hand-over barrier (DSTEP 2), ring of 6 tiles
+    case 80: *bm = 64; *bn = 64; return launch<64, 64, EPI, 6, 2, 2, 3, 0, 4, 2>(a, st);
+    case 81:
+      *bm = 64; *bn = 64;
+      if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 6, 2, 2, 3, 2, 4, 2>(a, st);
+      else return launch<64, 64, EPI, 6, 2, 2, 3, 1, 4, 2>(a, st);
+    case 82: *bm = 64; *bn = 128; return launch<64, 128, EPI, 6, 2, 4, 3, 0, 4, 2>(a, st);
+    case 83:
+      if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 128; return launch<64, 128, EPI, 6, 2, 4, 3, 1, 4, 2>(a, st); }
+      return -1;
     case 42:  // fused AdaLN, 4 loaders, 4 stages (what the dispatcher launches for the one-round producers)
       *bm = 64; *bn = 64;
       if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 4, 2, 2, 3, 2, 4>(a, st);
@@ -123,7 +154,7 @@ int main(int argc, char** argv) {
     a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = rps;
     if (epi == 3) { a.q = qb; a.k = kb; a.vt = vtb; a.n_pad = n_pad; a.heads = heads; a.rope_heads = heads; a.cos_sin = cs; }
     a.trace = trace + (size_t)l * max_grid * 48;
-    if (variant == 10 || (variant >= 40 && variant <= 42)) {
+    if (variant == 10 || (variant >= 40 && variant <= 42) || (variant >= 73 && variant <= 76) || variant == 81 || variant == 83) {
       a.row_mean = row_mean;
       if (epi == 2) { a.xs_out = out; a.ld_xs = N; a.next_scale = gate; a.stats_out = stats; }
       else { a.ln_stats = stats; a.ln_parts = K / 64; a.ln_c = cd; a.ln_d = cd + N; a.cd_stride = 2 * N; a.cd_rows = 1;
@@ -196,7 +227,7 @@ int main(int argc, char** argv) {
     }
     printf("\n");
   }
-  if (variant == 10 || (variant >= 40 && variant <= 42)) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
+  if (variant == 10 || (variant >= 40 && variant <= 42) || (variant >= 73 && variant <= 76) || variant == 81 || variant == 83) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
     std::vector<double> a42, a43, a44, a45, a40;
     const int l = L - 1;
     for (int w = 0; w < grid; ++w) {
