@@ -168,7 +168,12 @@ class CFM(nn.Module):
                sway_sampling_coef=None, seed: Optional[int] = None, max_duration=4096,
                vocoder: Optional[Callable] = None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
                edit_mask=None):
-        """reference model/cfm.py:349-482: pred + (pred - null) * cfg_strength, Euler/midpoint on the sway grid."""
+        """reference model/cfm.py:349-482: pred + (pred - null) * cfg_strength, Euler/midpoint on the sway grid.
+
+        Streams: everything this call launches runs on the CALLER's current stream (a private side stream only captures
+        graphs).  Calls from several threads on the default stream are correct but serialise; to overlap independent
+        utterances give each thread its own stream (`with torch.cuda.stream(s): cfm.sample(...)`, or
+        eval.eval_infer_batch.RankWorkers) -- loop states and memory pools are keyed by (thread, stream)."""
         prep = self._prepare(cond, text, duration, lens, steps, sway_sampling_coef, seed, max_duration, no_ref_audio,
                              duplicate_test, t_inter, edit_mask, use_text=True)
         if cfg_strength < 1e-5:
