@@ -748,13 +748,14 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
           if ((wide & 2) && a.N % 128 == 0 && blocks(64, 128) <= 256) {
 #ifdef F5E_TOOLS
             switch (role_var()) {
+              case 0: return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 0>(a, st);
               case 1: return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 1>(a, st);
               case 10: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st); break;
               case 11: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 1>(a, st); break;
             }
 #endif
+            // two K-tiles per hand-over: a fused consumer's K is a multiple of 256 (statistics parts % 4 == 0, set_consumer)
             if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st);
-            return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 0>(a, st);
           }
         }
       }

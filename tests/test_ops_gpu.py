@@ -617,3 +617,123 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     close(rm, xn.mean(1), 1e-4, 1e-5, "row mean moved along by the consumer")
     ref2 = (F.layer_norm(xn, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b
     assert float((out2.cpu() - ref2).pow(2).mean().sqrt()) / float(ref2.std()) < 4e-3
+
+
+# ------------------------------------------------------------------ role-split GEMMs (round 4): every instantiation by shape
+
+@pytest.mark.parametrize("S,N,H,K", [
+    (2, 469, 16, 1024),    # C2: 15 x 16 tiles of 64 x 192 on 256 CUs -> role split (12 consumer + 4 loader waves)
+    (3, 150, 12, 768),     # 8 x 12 wide tiles, D = 768 (the Small PPG model's widths)
+    (1, 1, 4, 256),        # a single row: one row tile, K = 4 tiles (the ring's depth)
+    (2, 131, 5, 512),      # odd rows per sequence, heads not a multiple of 4
+    (2, 640, 16, 1024),    # 20 x 16 = 320 wide tiles > 256: the classic 64 x 64 fused consumer
+])
+def test_fused_qkv_rope_consumer_role_split_and_classic(ops, S, N, H, K):
+    """f5e_gemm_bf16_qkv_rope_ln (fused AdaLN consumer + RoPE + fragment-major q / k / v^T): against the fp32 reference
+    LN(x)(1+scale)+shift -> linear -> RoPE (reference modules.py:308-314 + :452-480) and against the UNFUSED HIP ops
+    (f5e_layernorm + f5e_gemm_bf16_qkv_rope), at shapes that select the wide role-split kernel and the classic one."""
+    D, M, inner, P = K, S * N, H * 64, K // 64
+    n_pad = (N + 63) // 64 * 64
+    x = torch.randn(M, D, generator=g(80)) * 1.3 + 0.2
+    mod = torch.randn(1, 2 * D, generator=g(81)) * 0.3
+    scale, shift = mod[:, :D], mod[:, D:]
+    w = (torch.randn(3 * inner, D, generator=g(82)) / math.sqrt(D)).to(BF)
+    b = torch.randn(3 * inner, generator=g(83)) * 0.1
+    wf = w.float()
+    lin = ((F.layer_norm(x, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b).view(S, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    freqs = O.rope_freqs(N, 64)
+    q_ref, k_ref, v_ref = O.apply_rope(lin[0], freqs), O.apply_rope(lin[1], freqs), lin[2]
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    cs = torch.empty(N, 32, 2, device="cuda")
+    ops.rope_table(dev(inv), cs)
+    c = ((1 + scale) @ wf.T).contiguous()
+    dd = (shift @ wf.T + b).contiguous()
+    xd, modd = dev(x), dev(mod)
+    xs = torch.empty(M, D, device="cuda", dtype=BF)
+    stats = torch.empty(M, P, 2, device="cuda")
+    rm = torch.empty(M, device="cuda")
+    ops.adaln_pre(xd, xs, modd[:, :D], stats, rm, N)
+
+    def run(a, bias, ln):
+        q = torch.zeros(S, H, n_pad, 64, device="cuda", dtype=BF)
+        k = torch.zeros_like(q)
+        vt = torch.zeros(S, H, 64, n_pad, device="cuda", dtype=BF)
+        ops.gemm_bf16_qkv_rope(a, dev(w), bias, q, k, vt, H, H, cs, N, ln=ln)
+        return q, k, vt
+
+    qf, kf, vf = run(xs, None, ops.ln_consumer(stats, dev(c), dev(dd), N, rm))
+    hn = torch.empty(M, D, device="cuda", dtype=BF)
+    ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:], rows_per_seq=N)
+    qu, ku, vu = run(hn, dev(b), None)
+    qi, vi = ops.qk_frag_index(n_pad), ops.v_frag_index(n_pad)
+    unq = lambda t, idx: t.cpu().float().view(S, H, -1)[:, :, idx]   # noqa: E731
+    for name, fused, unf, ref, idx, sc in (("q", qf, qu, q_ref, qi, QSCALE), ("k", kf, ku, k_ref, qi, 1.0), ("v", vf, vu, v_ref, vi, 1.0)):
+        got, base, want = unq(fused, idx)[:, :, :N], unq(unf, idx)[:, :, :N], ref * sc
+        spread = float(want.std())
+        e_f, e_u = float((got - want).abs().max()) / spread, float((base - want).abs().max()) / spread
+        assert e_f < 4e-2 and e_f < 2.5 * e_u + 2e-3, (name, e_f, e_u)     # bf16-level, on par with the unfused path
+        assert float((got - want).pow(2).mean().sqrt()) / spread < 5e-3, name
+        if n_pad > N:
+            assert float(unq(fused, idx)[:, :, N:].abs().max()) == 0         # pad positions are never written
+
+
+@pytest.mark.parametrize("S,N,D,NO,K_unused", [
+    (2, 469, 1024, 2048, 0),   # C2's FF1: 15 x 16 tiles of 64 x 128, two K-tiles per hand-over (K % 128 == 0)
+    (1, 77, 256, 256, 0),      # K = 256: four K-tiles = less than the ring of six, two row tiles
+    (3, 150, 768, 1536, 0),    # the Small PPG model's FF1
+    (2, 469, 1024, 2176, 0),   # 17 column tiles x 15 = 255: still one round
+    (2, 469, 1024, 2304, 0),   # 18 x 15 = 270 > 256: the classic consumer
+])
+def test_fused_gelu_consumer_role_split_and_classic(ops, S, N, D, NO, K_unused):
+    """f5e_gemm_bf16_bias_ln with GELU(tanh) (FF1 behind the fused AdaLN, reference modules.py:637 + :348-349) on the wide
+    role-split tiles and on the classic ones: against fp32 and against the unfused HIP ops."""
+    M, P = S * N, D // 64
+    x = torch.randn(M, D, generator=g(84)) * 1.2 - 0.4
+    mod = torch.randn(1, 2 * D, generator=g(85)) * 0.3
+    scale, shift = mod[:, :D], mod[:, D:]
+    w = (torch.randn(NO, D, generator=g(86)) / math.sqrt(D)).to(BF)
+    b = torch.randn(NO, generator=g(87)) * 0.1
+    wf = w.float()
+    ref = F.gelu((F.layer_norm(x, (D,), eps=1e-6) * (1 + scale) + shift) @ wf.T + b, approximate="tanh")
+    c, dd = ((1 + scale) @ wf.T).contiguous(), (shift @ wf.T + b).contiguous()
+    xd, modd = dev(x), dev(mod)
+    xs = torch.empty(M, D, device="cuda", dtype=BF)
+    stats = torch.empty(M, P, 2, device="cuda")
+    rm = torch.empty(M, device="cuda")
+    ops.adaln_pre(xd, xs, modd[:, :D], stats, rm, N)
+    out = torch.empty(M, NO, device="cuda", dtype=BF)
+    ops.gemm_bf16_bias(xs, dev(w), None, out, act=ops.ACT_GELU_TANH, ln=ops.ln_consumer(stats, dev(c), dev(dd), N, rm))
+    hn = torch.empty(M, D, device="cuda", dtype=BF)
+    ops.layernorm(xd, hn, scale=modd[:, :D], shift=modd[:, D:], rows_per_seq=N)
+    unf = torch.empty(M, NO, device="cuda", dtype=BF)
+    ops.gemm_bf16_bias(hn, dev(w), dev(b), unf, act=ops.ACT_GELU_TANH)
+    spread = float(ref.std())
+    e_f, e_u = float((out.cpu().float() - ref).abs().max()) / spread, float((unf.cpu().float() - ref).abs().max()) / spread
+    assert e_f < 4e-2 and e_f < 2.5 * e_u + 2e-3, (e_f, e_u)
+    assert float((out.cpu().float() - ref).pow(2).mean().sqrt()) / spread < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K,rps", [
+    (938, 1024, 1024, 469),   # out-projection at C2: ring of 6, two K-tiles per hand-over
+    (938, 1024, 2048, 469),   # FF2 at C2
+    (200, 256, 192, 50),      # K = 192: one tile per hand-over, 4-stage ring, 4 sequences
+    (64, 64, 64, 64),         # a single tile, a single K-tile
+    (1, 128, 128, 1),         # one row
+    (130, 1024, 320, 65),     # K = 320 (5 tiles: odd count), a partial last row tile
+])
+def test_gate_residual_role_split_matches_reference(ops, M, N, K, rps):
+    """The one-round gate+residual GEMM (role split) without the AdaLN producer: x += gate * (a @ w.T + b) in fp32, masked
+    rows untouched (reference modules.py:494-501, 635, 639)."""
+    S = M // rps
+    a = torch.randn(M, K, generator=g(88)).to(BF)
+    w = (torch.randn(N, K, generator=g(89)) / math.sqrt(K)).to(BF)
+    b = torch.randn(N, generator=g(90)) * 0.1
+    gate = torch.randn(1, N, generator=g(91)) * 0.5
+    x = torch.randn(M, N, generator=g(92))
+    seq_len = torch.tensor([max(1, rps - 3 * i) for i in range(S)], dtype=torch.int32)
+    live = (torch.arange(M) % rps)[:, None] < seq_len[torch.arange(M) // rps][:, None]
+    ref = torch.where(live, x + gate * (a.float() @ w.float().T + b), x)
+    xd = dev(x)
+    ops.gemm_bf16_gate_residual(dev(a), dev(w), dev(b), xd, dev(gate), rps, seq_len=dev(seq_len))
+    close(xd, ref, 1e-3, 2e-3, "gated residual update")
+    assert torch.equal(xd.cpu()[~live.expand_as(x)], x[~live.expand_as(x)])   # masked rows: bit-identical

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-T=tools/gemm_trace.bin
-for v in 10 74; do timeout -k 5 60 $T $v 938 3072 1024 3 || exit 1; done > gpurun_out/r04x_trace_qkv.txt 2>&1
-grep -h "variant\|per workgroup\|per launch\|consumer epi" gpurun_out/r04x_trace_qkv.txt
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_e2e_gpu.py -x -q -m gpu > gpurun_out/r04x_tests.log 2>&1 || { tail -30 gpurun_out/r04x_tests.log; exit 1; }
-tail -2 gpurun_out/r04x_tests.log
-python bench.py --no-cpu-baseline --no-c3 --c4-total 0 --streams 0 --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['all_ops_us'])"
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu > gpurun_out/r04y_ops.log 2>&1 || { tail -40 gpurun_out/r04y_ops.log; exit 1; }
+tail -2 gpurun_out/r04y_ops.log
+timeout -k 10 420 python tools/fuzz_ops.py 300 51 > gpurun_out/r04y_fuzz_ops.log 2>&1; tail -3 gpurun_out/r04y_fuzz_ops.log
+timeout -k 10 300 python tools/fuzz_model.py 200 52 > gpurun_out/r04y_fuzz_model.log 2>&1; tail -3 gpurun_out/r04y_fuzz_model.log
