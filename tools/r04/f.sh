@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu > gpurun_out/r04y_ops.log 2>&1 || { tail -40 gpurun_out/r04y_ops.log; exit 1; }
-tail -2 gpurun_out/r04y_ops.log
-timeout -k 10 420 python tools/fuzz_ops.py 300 51 > gpurun_out/r04y_fuzz_ops.log 2>&1; tail -3 gpurun_out/r04y_fuzz_ops.log
-timeout -k 10 300 python tools/fuzz_model.py 200 52 > gpurun_out/r04y_fuzz_model.log 2>&1; tail -3 gpurun_out/r04y_fuzz_model.log
+T=tools/gemm_trace.bin
+run() { out=$1; shift; M=$1; N=$2; K=$3; E=$4; shift 4; for v in "$@"; do timeout -k 5 90 $T $v $M $N $K $E || { echo "variant $v failed"; exit 1; }; done > gpurun_out/$out 2>&1; }
+run r04ab_trace_out.txt 938 1024 1024 2   80 90 91 93 81 92 || { cat gpurun_out/r04ab_trace_out.txt | tail -5; exit 1; }
+run r04ab_trace_ff2.txt 938 1024 2048 2   80 91 81 92 || exit 1
+grep -h "variant\|per launch\|K-step" gpurun_out/r04ab_trace_*.txt
