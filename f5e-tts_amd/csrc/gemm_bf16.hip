@@ -57,14 +57,12 @@ __device__ __forceinline__ void wait_stages(int nst) {
 // DSTEP (role split only): K-tiles per hand-over barrier.  A barrier is a full rendezvous of loaders and consumers and costs
 // ~100 cycles of skew per K-step on top of max(loader issue, consumer reads + MFMAs); handing over TWO tiles per barrier
 // halves that (K % 128 == 0; ring of NSTAGE >= 3 DSTEP tiles: DSTEP being read, DSTEP landed or landing, DSTEP being issued).
-// FETCH (role split only): where the consumers request the epilogue operands (x tile, gate, statistics: ~14 loads per lane,
-// ~1000 cycles of the address path per workgroup, latency of a cold line from the Infinity Cache or HBM).
-//   0: behind the first hand-over barrier (they stall that K-step's issue);  1: behind an extra barrier that the loaders join
-//   once their prologue DMAs are issued -- the address path idles from there until the first tile lands.
-// (At kernel entry they delay the first tile by ~640 cycles.  Over the LAST K-tiles, where the loaders fall silent, they come
-// back too late in the block chain: measured slower in situ, 42.3 vs 40.1 ms per C2 pass.)
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0, int DSTEP = 1,
-          int FETCH = 0>
+// Role split: the consumers request the epilogue operands (x tile, gate, statistics: ~14 loads per lane, ~1000 cycles of the
+// address path per workgroup, a cold line's latency from the Infinity Cache or HBM) behind the FIRST hand-over.  Measured
+// alternatives (DESIGN 4 "Round 4"): at kernel entry they delay the first tile by ~640 cycles; behind an extra barrier that
+// follows the loaders' prologue issue: 41.9 vs 40.9 ms per C2 pass; over the LAST K-tiles, where the loaders fall silent:
+// fastest stand-alone, 42.3 ms in situ (the x tile is not back when the epilogue wants it).
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0, int DSTEP = 1>
 __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
@@ -194,7 +192,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       // argument as the classic ring, per step of DSTEP tiles.
       int nbuf_l = NPRO % NSTAGE;
       if constexpr (DBG == 3) { if (stid == 0) trc[47] = __builtin_amdgcn_s_memtime(); }
-      if (FETCH == 1) __builtin_amdgcn_s_barrier();   // prologue issued: the consumers may use the address path now
       for (int kt = 0; kt < KT; kt += DSTEP) {
         // issued so far: tiles [0, min(KT, kt + NPRO)); all but the ones younger than this step's tiles must have landed:
         // min(tiles behind this step, NSTAGE - 2 DSTEP) may stay in flight
@@ -348,13 +345,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       if (DSTEP == 1 || P == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next hand-over
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     };
-    if (FETCH == 1) {
-      __builtin_amdgcn_s_barrier();                    // the loaders' prologue DMAs are issued (see FETCH)
-      fetch_epilogue_operands();
-    }
     for (int kt = 0; kt < KT; kt += 2) {
       body(std::integral_constant<int, 0>{}, kt);
-      if (FETCH == 0 && kt == 0) fetch_epilogue_operands();
+      if (kt == 0) fetch_epilogue_operands();
       if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
     }
     if ((KT - 1) & 1) mfmas(std::integral_constant<int, 1>{});
@@ -652,8 +645,7 @@ inline int pick_group_shift(int tiles_m, int tiles_n, int bm, int bn) {
   return best_s;
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1,
-          int FETCH = 0>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -674,8 +666,8 @@ int launch(GemmArgs& a, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, FETCH>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, FETCH>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -689,7 +681,7 @@ inline bool role_split_on() {
 #endif
   return true;
 }
-// diagnostics build only: F5E_GEMM_VAR = 10 * dstep_variant + fetch_variant picks among the role-split instantiations
+// diagnostics build only: F5E_GEMM_VAR=0 -> one K-tile per hand-over (4- / 3-stage rings) instead of two on a ring of six
 inline int role_var() {
 #ifdef F5E_TOOLS
   if (const char* f = getenv("F5E_GEMM_VAR")) return atoi(f);
@@ -710,20 +702,10 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       // one-round grids (out-projection / FF2 at batch 1: 240 workgroups on 256 CUs): role split, 4 loader + 4 consumer
       // waves, 4-stage ring -- see the NLOAD note at the kernel
       if (role_split_on() && blocks(64, 64) <= 256) {
-#ifdef F5E_TOOLS
-        switch (role_var()) {
-          case 0: return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 0>(a, st);
-          case 1: return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 1>(a, st);
-          case 10: if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 0>(a, st); break;
-          case 11: if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 1>(a, st); break;
-          case 20: if (a.K % 128 == 0) return launch<64, 64, EPI, 8, 2, 2, 0, 2, 4, 2, 0>(a, st); break;
-          case 30: return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 1, 0>(a, st);
-        }
-#endif
         // two K-tiles per hand-over barrier on a ring of six (in situ at C2, ms per pass: classic ring 41.4; 4 stages, one tile
         // per barrier 40.9; this 40.7; 8-tile ring 41.2; 6 stages, one tile per barrier 41.8)
-        if (a.K % 128 == 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2, 0>(a, st);
-        return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1, 0>(a, st);
+        if (a.K % 128 == 0 && role_var() != 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2>(a, st);
+        return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1>(a, st);   // K % 128 != 0 (or F5E_GEMM_VAR=0 in the diagnostics build)
       }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
@@ -739,23 +721,15 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
 #endif
         if constexpr (EPI == EPI_QKV_ROPE) {
           if ((wide & 1) && a.N % 192 == 0 && blocks(64, 192) <= 256) {
-#ifdef F5E_TOOLS
-            if (role_var() % 10 == 1) return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1, 1>(a, st);
-#endif
-            return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1, 0>(a, st);
+            return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1>(a, st);
           }
         } else {
           if ((wide & 2) && a.N % 128 == 0 && blocks(64, 128) <= 256) {
 #ifdef F5E_TOOLS
-            switch (role_var()) {
-              case 0: return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 0>(a, st);
-              case 1: return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1, 1>(a, st);
-              case 10: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st); break;
-              case 11: if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 1>(a, st); break;
-            }
+            if (role_var() == 0) return launch<64, 128, EPI, 3, 2, 4, 0, 1, 4, 1>(a, st);   // diagnostics build: one tile per hand-over
 #endif
             // two K-tiles per hand-over: a fused consumer's K is a multiple of 256 (statistics parts % 4 == 0, set_consumer)
-            if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2, 0>(a, st);
+            if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2>(a, st);
           }
         }
       }
