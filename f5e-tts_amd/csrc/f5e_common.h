@@ -105,6 +105,26 @@ __device__ __forceinline__ void f5e_prefetch_run(const F5ePrefetch& pf, int wg, 
   }
 }
 
+// The same with a RUN-TIME granule (a multiple of NT * 16 bytes): the role-split GEMMs of a one-round grid occupy one CU per
+// workgroup (their LDS ring excludes a second one), so prefetch workgroups cannot start beside them -- they queue for the
+// CUs the main grid leaves idle.  Those launches therefore pack the whole prefetch into exactly as many workgroups as there
+// are idle CUs (gemm_bf16.hip launch()), each walking a longer slice.
+__device__ __forceinline__ void f5e_prefetch_run_packed(const F5ePrefetch& pf, int wg, int tid, int nt, unsigned per_wg,
+                                                        void* lds) {
+  unsigned long long off = (unsigned long long)wg * per_wg + (unsigned)tid * 16u;
+  const unsigned long long end = (unsigned long long)(wg + 1) * per_wg;
+  const unsigned long long b0 = pf.ptr[0] ? pf.bytes[0] : 0, b1 = pf.ptr[1] ? pf.bytes[1] : 0;
+  char* dst = (char*)lds + (tid >> 6) * 1024;
+  for (; off < end; off += (unsigned)nt * 16u) {
+    const char* p = nullptr;
+    if (off + 16 <= b0) p = (const char*)pf.ptr[0] + off;
+    else if (off >= b0 && off - b0 + 16 <= b1) p = (const char*)pf.ptr[1] + (off - b0);
+    if (p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
 // internal entry points with a prefetch hint (gemm_bf16.hip, attention.hip), used by f5e_dit_forward
 int f5e_gemm_bf16_bias_pf(hipStream_t st, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                           int ldo, int M, int N, int K, int act, int out_f32, int tile_hint, const f5e_ln_fuse* ln,

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   if (EPI == EPI_QKV_ROPE) asm volatile("" ::"s"(a.q), "s"(a.k), "s"(a.vt), "s"(a.cos_sin), "s"(a.n_pad), "s"(a.heads), "s"(a.rope_heads));
 
   if ((int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h), 256 threads of them
-    if (tid < 256) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
+    if (NLOAD > 0 && a.pf_per_wg) f5e_prefetch_run_packed(a.pf, (int)blockIdx.x - a.n_main, tid, 64 * (NCW + NLOAD), a.pf_per_wg, smem);
+    else if (tid < 256) f5e_prefetch_run(a.pf, (int)blockIdx.x - a.n_main, tid, smem);
     return;
   }
   // XCD-aware tile order: blocks that share blockIdx%8 (one XCD) walk tiles with the same n-panel.
@@ -645,6 +646,14 @@ inline int pick_group_shift(int tiles_m, int tiles_n, int bm, int bn) {
   return best_s;
 }
 
+// diagnostics build only: F5E_PF_PACK=0 -> 32 KiB prefetch workgroups everywhere (the round-3 layout)
+inline bool pack_prefetch_on() {
+#ifdef F5E_TOOLS
+  if (const char* f = getenv("F5E_PF_PACK")) return atoi(f) != 0;
+#endif
+  return true;
+}
+
 template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
@@ -661,7 +670,20 @@ int launch(GemmArgs& a, hipStream_t st) {
   a.rps_magic = div_magic_of(a.rows_per_seq);
   a.n_main = a.tiles_m * a.tiles_n;
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
-  const int grid = a.n_main + (((WGM * WGN == 4 || NLOAD > 0) && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0);
+  int pf_wgs = ((WGM * WGN == 4 || NLOAD > 0) && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0;
+  a.pf_per_wg = 0;
+  constexpr int lds_probe = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
+  if (NLOAD > 0 && 2 * lds_probe > 160 * 1024 && pf_wgs > 0 && pack_prefetch_on()) {
+    // one workgroup per CU (LDS): the prefetch goes to the CUs the main grid leaves idle, one packed workgroup each
+    const int idle = f5e_cu_count() - a.n_main;
+    if (idle > 0 && pf_wgs > idle) {
+      constexpr unsigned gran = 64u * (WGM * WGN + NLOAD) * 16u;   // one LDS-DMA of every thread of the workgroup
+      const unsigned long long total = (unsigned long long)pf_wgs * F5E_PF_BYTES_PER_WG;
+      a.pf_per_wg = (unsigned)(((total + idle - 1) / idle + gran - 1) / gran * gran);
+      pf_wgs = (int)((total + a.pf_per_wg - 1) / a.pf_per_wg);
+    }
+  }
+  const int grid = a.n_main + pf_wgs;
   if (grid == a.n_main) a.pf = F5ePrefetch{};
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");

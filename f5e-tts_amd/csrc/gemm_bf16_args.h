@@ -50,6 +50,7 @@ struct GemmArgs {
   float* row_mean;
   int pp_ngroup;   // gemm_bf16_pp.hip: n-tiles per column group of the tile order (0 = plain m-major)
   F5ePrefetch pf;  // weights of the next kernels, pulled into the Infinity Cache by grid-tail workgroups (small M only)
+  unsigned pf_per_wg;  // 0: 32 KiB per prefetch workgroup; else the packed granule (bytes) of f5e_prefetch_run_packed
 };
 
 static_assert(offsetof(GemmArgs, n_main) + sizeof(int) == 64, "hot kernarg fields must fill exactly the first 64-byte line");

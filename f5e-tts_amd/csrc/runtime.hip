@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <cstdlib>
+
 #include "f5e_common.h"
 #include "gemm_bf16_args.h"
 
@@ -234,9 +236,38 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
       const float* cdl = p->cd + (size_t)l * ls;
       const F5ePrefetch pf_next{{l + 1 < p->L ? p->blocks[l + 1].w_qkv : p->w_proj, nullptr},
                                 {l + 1 < p->L ? b_qkv : (unsigned)((size_t)p->mel * D * 2), 0}};
-      const F5ePrefetch pf_qkv{{w.w_out, nullptr}, {b_out, 0}};
-      const F5ePrefetch pf_attn{{w.w_ff1, nullptr}, {b_ff, 0}};
-      const F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
+      F5ePrefetch pf_qkv{{w.w_out, nullptr}, {b_out, 0}};
+      F5ePrefetch pf_attn{{w.w_ff1, nullptr}, {b_ff, 0}};
+      F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
+      F5ePrefetch pf_nx = pf_next, pf_ff1{};
+#ifdef F5E_TOOLS
+      {  // diagnostics build only: hosting schemes for A/B (F5E_PF_SCHEME)
+        static const int scheme = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : 0;
+        const void* wout_next = l + 1 < p->L ? (const void*)p->blocks[l + 1].w_out : nullptr;
+        if (scheme == 1 || scheme == 3) {   // attention hosts both FF weights, the out-projection nothing
+          pf_attn = F5ePrefetch{{w.w_ff1, w.w_ff2}, {b_ff, b_ff}};
+          pf_out = F5ePrefetch{};
+        }
+        if (scheme == 2 || scheme == 3) {   // FF2 hosts the next block's w_qkv AND w_out, QKV nothing
+          pf_nx = F5ePrefetch{{pf_next.ptr[0], wout_next}, {pf_next.bytes[0], wout_next ? b_out : 0}};
+          if (l > 0) pf_qkv = F5ePrefetch{};
+        }
+        if (scheme == 5 || scheme == 6) {   // the GEMMs host everything, attention nothing
+          pf_qkv = F5ePrefetch{{w.w_out, w.w_ff1}, {b_out, b_ff}};
+          pf_attn = F5ePrefetch{};
+          if (scheme == 6) { pf_out = F5ePrefetch{}; pf_ff1 = F5ePrefetch{{w.w_ff2, nullptr}, {b_ff, 0}}; }
+        }
+        if (scheme == 7) {                  // just in time: every GEMM hosts the weights of the next GEMM
+          pf_attn = F5ePrefetch{};
+          pf_out = F5ePrefetch{{w.w_ff1, nullptr}, {b_ff, 0}};
+          pf_ff1 = F5ePrefetch{{w.w_ff2, nullptr}, {b_ff, 0}};
+        }
+        if (scheme == 4) {                  // attention hosts w_ff1 and the next block's w_qkv, FF2 nothing
+          pf_attn = F5ePrefetch{{w.w_ff1, pf_next.ptr[0]}, {b_ff, pf_next.bytes[0]}};
+          pf_nx = F5ePrefetch{};
+        }
+      }
+#endif
       cons.c = cdl; cons.d = cdl + 3 * inner;
       F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_pf(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
                                         p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons, pfon ? &pf_qkv : nullptr));
@@ -248,12 +279,12 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
                                           inner, 0, &prod, pfon ? &pf_out : nullptr));
       cons.c = cdl + 6 * inner; cons.d = cdl + 6 * inner + p->FF;
       F5E_TIMED(F5E_OP_FF1, f5e_gemm_bf16_bias_pf(st, p->hn, D, w.w_ff1, D, nullptr, p->ff, p->FF, M, p->FF, D,
-                                    F5E_ACT_GELU_TANH, 0, 0, &cons, nullptr));
+                                    F5E_ACT_GELU_TANH, 0, 0, &cons, pfon && pf_ff1.ptr[0] ? &pf_ff1 : nullptr));
       // next norm: attn_norm of block l+1 (scale_msa at +D) or the final AdaLN (scale first: modules.py:333)
       prod.next_scale = (l + 1 < p->L) ? mb + 6 * D + D : p->mod + (size_t)p->L * 6 * D;
       F5E_TIMED(F5E_OP_FF2, f5e_gemm_bf16_gate_residual_pf(st, p->ff, p->FF, w.w_ff2, p->FF, w.b_ff2, p->x, D, mb + 5 * D,
                                           row_stride, p->mod_rows, p->eval_ptr, eval_stride, p->N, nullptr, M, D, p->FF,
-                                          0, &prod, pfon ? &pf_next : nullptr));
+                                          0, &prod, pfon ? &pf_nx : nullptr));
     }
     cons.c = p->cd + (size_t)p->L * ls; cons.d = cons.c + p->mel;
     F5E_TIMED(F5E_OP_FINAL, f5e_gemm_bf16_bias_ln(st, p->hn, D, p->w_proj, D, nullptr, p->pred, p->mel, M, p->mel, D,
