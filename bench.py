@@ -543,8 +543,9 @@ def main():
                         "all_ops_frac": {k: v["frac"] for k, v in rp.items()},
                         "block_sum_us": round(sum(v["avg_us"] for v in rp.values()), 2)},
                     "rocprof_note": rp_note,
-                    "pmc_mfma": None if pm is None else {k: {x: v.get(x) for x in ("mfma_busy", "eff_clock_ghz", "wave_cycles_parked")}
-                                                         for k, v in pm.items()},
+                    "pmc_mfma": None if pm is None else {k: {x: v.get(x) for x in ("mfma_busy", "eff_clock_ghz", "wave_cycles_parked",
+                                                                                   "counter_window_over_span", "mfma_busy_span_min")
+                                                             if x in v} for k, v in pm.items()},
                     "pmc_mfma_note": pm_note}
 
     roofline_c3 = None

@@ -9,8 +9,8 @@ kernel sources (tools/src_hash.py) so that bench.py can carry them in its line b
       per op, from ONE eager pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAIT_ANY (SQ block) and GRBM_GUI_ACTIVE:
       mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8)   (busy cycles are summed over
       the SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs; MI355X_MICROARCH.md, DVFS note), eff_clock_ghz = GRBM_GUI_ACTIVE / 8 /
-      kernel wall time (reads high on dispatches shorter than ~0.3 ms, same note), wave_cycles_parked = SQ_WAIT_ANY /
-      SQ_WAVE_CYCLES.
+      kernel wall time (reads high on dispatches shorter than ~0.3 ms, same note: derive() below nulls it when it exceeds
+      the chip's 2.4 GHz and adds mfma_busy_span_min), wave_cycles_parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES.
 
 The two gate+residual GEMMs of a block (out-projection, FF2) run the SAME kernel instantiation, so ops are told apart by
 launch order inside a block: ... QKV, attention, OUT, FF1, FF2 ... -- a gate+residual launch behind attention is OUT,
@@ -66,7 +66,41 @@ def med(v):
     return s[len(s) // 2]
 
 
+MAX_CLOCK_GHZ = 2.4
+
+
+def derive(row, c, us):
+    """Ratios of one op from its averaged counters and its kernel span (us).  GRBM_GUI_ACTIVE covers the dispatch's whole
+    counter window (command processor, launch, drain), not only begin -> end of the kernel: on a 10 us launch the window is
+    1.4-1.7 x the span, so mfma_busy (busy / window) reads LOW and eff_clock_ghz (window cycles / span) reads above the
+    2.4 GHz the chip can clock.  Such rows get eff_clock_ghz = null and mfma_busy_span_min = busy cycles / (1024 SIMDs x
+    span x 2.4 GHz): the matrix pipe's share of the kernel's own span if the clock was at its maximum (a lower clock means
+    a higher share)."""
+    if c.get("GRBM_GUI_ACTIVE"):
+        row["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)
+        row["eff_clock_ghz"] = round(clk, 3)
+        if clk > MAX_CLOCK_GHZ * 1.02:
+            row["eff_clock_ghz"] = None
+            row["counter_window_over_span"] = round(clk / MAX_CLOCK_GHZ, 2)
+            row["mfma_busy_span_min"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * us * 1e3 * MAX_CLOCK_GHZ), 4)
+    if c.get("SQ_WAVE_CYCLES"):
+        row["wave_cycles_parked"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+
+
 def main():
+    if sys.argv[1] == "redigest":   # prof_ops.py redigest <ops_pmc json>: re-derive the ratios from the stored counters
+        res = json.load(open(sys.argv[2]))
+        for row in res["ops"].values():
+            for k in ("mfma_busy", "eff_clock_ghz", "wave_cycles_parked", "counter_window_over_span", "mfma_busy_span_min"):
+                row.pop(k, None)
+            derive(row, row["counters"], row["avg_us_under_pmc"])
+        note = ("; short dispatches: eff_clock_ghz null where the counter window exceeds the kernel span (window / span given), "
+                "mfma_busy_span_min = busy cycles / (1024 SIMDs x span x 2.4 GHz)")
+        if note not in res.get("source", ""):
+            res["source"] = res.get("source", "") + note
+        json.dump(res, open(sys.argv[2], "w"), indent=1)
+        return
     mode, d, w, outp = sys.argv[1:5]
     res = {"workload": w, "csrc_sha256": csrc_sha256(), "peak_tflops": PEAK, "ops": {}}
     if mode == "trace":
@@ -100,14 +134,12 @@ def main():
             c = {k: sum(r["c"].get(k, 0.0) for r in v) / n for k in v[0]["c"]}
             us = sum(r["t1"] - r["t0"] for r in v) / n * 1e-3
             row = {"launches": n, "avg_us_under_pmc": round(us, 3), "counters": {k: round(x, 1) for k, x in c.items()}}
-            if c.get("GRBM_GUI_ACTIVE"):
-                row["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
-                row["eff_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3), 3)
-            if c.get("SQ_WAVE_CYCLES"):
-                row["wave_cycles_parked"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+            derive(row, c, us)
             res["ops"][o] = row
         res["source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE, one eager pass; "
-                         "mfma_busy = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
+                         "mfma_busy = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+                         "; short dispatches: eff_clock_ghz null where the counter window exceeds the kernel span (window / span given), "
+                         "mfma_busy_span_min = busy cycles / (1024 SIMDs x span x 2.4 GHz)")
     json.dump(res, open(outp, "w"), indent=1)
     for o in ("QKV", "ATTN", "OUT", "FF1", "FF2"):
         if o in res["ops"]:

@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-T="F5E_HIP_LIB=$GRAFT_REPO_ROOT/f5e-tts_amd/libf5e_hip_tools.so"
-bash tools/gpu_ab.sh r04ae --args "--no-c3 --c4-total 0 --streams 0 --steps 20" "$T F5E_PF_SCHEME=0" "$T F5E_PF_SCHEME=1" "$T F5E_PF_SCHEME=5" "$T F5E_PF_SCHEME=6" "$T F5E_PF_SCHEME=7" "$T F5E_PF_SCHEME=0" "$T F5E_PF_SCHEME=1" "$T F5E_PF_SCHEME=5" "$T F5E_PF_SCHEME=6" "$T F5E_PF_SCHEME=7"
+SKIP_MFMA=1 bash tools/gpu_profile.sh r04af > gpurun_out/r04af_profile.log 2>&1 || { tail -20 gpurun_out/r04af_profile.log; exit 1; }
+grep -E "^(QKV|ATTN|OUT|FF1|FF2) " gpurun_out/r04af_profile.log
+timeout -k 10 900 python bench.py > gpurun_out/r04af_bench_c2_default.json 2> gpurun_out/r04af_bench_c2_default.err || { tail -20 gpurun_out/r04af_bench_c2_default.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04af_bench_c2_default.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d.get('scaling_c4'), (d.get('concurrent') or {}).get('value'), d.get('c3',{}).get('value') if isinstance(d.get('c3'),dict) else None)
+PY
