@@ -62,7 +62,13 @@ __device__ __forceinline__ void wait_stages(int nst) {
 // alternatives (DESIGN 4 "Round 4"): at kernel entry they delay the first tile by ~640 cycles; behind an extra barrier that
 // follows the loaders' prologue issue: 41.9 vs 40.9 ms per C2 pass; over the LAST K-tiles, where the loaders fall silent:
 // fastest stand-alone, 42.3 ms in situ (the x tile is not back when the epilogue wants it).
-template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0, int DSTEP = 1>
+// DBUF (role split only): 1 = the consumers double-buffer their fragments in registers (reads of tile kt under the MFMAs of
+// tile kt - 1); 0 = ONE fragment set whose two 32-k halves take turns (reads of one half under the MFMAs of the other) for the
+// consumers of 64 x 32 wave tiles, whose VGPR budget (128 at 16 waves, 168 at 12) does not hold two full sets.
+// 128-row tiles (round 4, M in (1024, 2048]: C4's utterance lengths): the same role-split kernels on 128 x 64 (producer, 8
+// consumer waves of 32 x 32), 128 x 128 and 128 x 192 (consumers, 8 / 12 waves of 64 x 32) -- again a ONE-round grid of at
+// most 16 x 16 tiles, where the 64-row tiles would need two rounds of classic three-per-CU workgroups.
+template <int BM, int BN, int EPI, int NSTAGE, int DBG = 0, int WGM = 2, int WGN = 2, int FUSE = 0, int NLOAD = 0, int DSTEP = 1, int DBUF = 1>
 __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(GemmArgs a) {
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;                    // 16-byte chunks per LDS row
@@ -223,8 +229,13 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   constexpr bool PREF = (TM * TN <= 4);
   // fused AdaLN: 64-row tiles of 32 x 32 wave sub-tiles (row statistics: 4 threads per row = the first 256 threads); the
   // producer is 64 x 64, a role-split consumer may be wider (64 x 128 / 64 x 192: the A panel is staged once per K-step)
-  static_assert(FUSE == 0 || (PREF && BM == 64 && WGM == 2 && BN == 32 * WGN && (BN == 64 || (FUSE == 1 && NLOAD > 0))),
-                "fused AdaLN: 64-row tiles, 32 x 32 wave sub-tiles");
+  static_assert(FUSE != 2 || (PREF && WM == 32 && WN == 32 && BN == 64 && (BM == 64 || (BM == 128 && NLOAD > 0))),
+                "fused AdaLN producer: 64 (or, role split, 128) x 64 tiles of 32 x 32 wave sub-tiles");
+  static_assert(FUSE != 1 || (WN == 32 && (BN == 64 || NLOAD > 0) && ((BM == 64 && WM == 32) || (BM == 128 && WM == 64 && NLOAD > 0))),
+                "fused AdaLN consumer: 64-row tiles of 32 x 32 wave sub-tiles, or (role split) 128-row tiles of 64 x 32 ones");
+  static_assert(DBUF == 1 || (NLOAD > 0 && DSTEP == 1), "single fragment set: role split, one tile per hand-over");
+  constexpr int NSTATT = BM * 4;   // fused consumer: 4 threads per row of the tile work out its statistics
+  static_assert(FUSE != 1 || NSTATT <= NC, "fused consumer: 4 statistics threads per row");
   static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
   constexpr int NPC = NLOAD ? 0 : (FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0)));
   static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
@@ -278,8 +289,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       const unsigned rel_max = (unsigned)((a.M - m0) * a.ln_parts - 1);       // last valid pair of the tile's rows
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned rel = min((unsigned)((tid & 255) * pp + min(u, pp - 1)), rel_max);
-        if (NC == 256 || tid < 256) pf_st[u] = *(const f32x2*)(sbase + rel * 2u);   // counted (classic: every thread)
+        const unsigned rel = min((unsigned)((tid & (NSTATT - 1)) * pp + min(u, pp - 1)), rel_max);
+        if (NC == NSTATT || tid < NSTATT) pf_st[u] = *(const f32x2*)(sbase + rel * 2u);   // counted (classic: every thread)
       }
     }
     if (PREF) {  // not counted: may be skipped
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
     // ---- consumer waves of a role-split launch.  Step kt: pass the barrier that hands tile kt over, issue its fragment
     // reads into one register set, run the MFMAs of tile kt - 1 from the other set under those reads, and retire the reads
     // (lgkmcnt(0)) BEFORE the next barrier -- behind it the loader refills the buffer just read.
-    bf16x8 xs2[2][BK / 32][TM], ws2[2][BK / 32][TN];
+    bf16x8 xs2[DBUF + 1][BK / 32][TM], ws2[DBUF + 1][BK / 32][TN];
     auto reads = [&](auto pc, int b) {
       constexpr int P = decltype(pc)::value;
       const char* As = ring + b * STAGE;
@@ -346,13 +357,57 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       if (DSTEP == 1 || P == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next hand-over
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     };
-    for (int kt = 0; kt < KT; kt += 2) {
-      body(std::integral_constant<int, 0>{}, kt);
-      if (kt == 0) fetch_epilogue_operands();
-      if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
+    if constexpr (DBUF == 0) {
+      // ONE fragment set, pipelined by HALF K-tiles (kk = 0 / 1: 32 of the tile's 64 k): the set's two halves take turns --
+      // the reads of one half are in flight under the MFMAs of the other, as with two full sets but in half the registers.
+      // Every wave passes the hand-over barrier at the same time, so without this all waves of the CU read (LDS-bound),
+      // then all multiply (pipe-bound), and the two phases add up.  Reads of tile kt are retired before the barrier of
+      // tile kt + 1 (the last wait of the step), behind which the loader refills tile kt - 1's ... kt's buffers in turn.
+      auto reads_half = [&](int kk, int b) {
+        const char* As = ring + b * STAGE;
+        const char* Ws = As + A_BYTES;
+        const int c = kk * 4 + fq;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int row = wm0 + j * 16 + fr;
+          xs2[0][kk][j] = *(const bf16x8*)(As + row * ROWB + ((c ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int row = wn0 + i * 16 + fr;
+          ws2[0][kk][i] = *(const bf16x8*)(Ws + row * ROWB + ((c ^ swz(row)) << 4));
+        }
+      };
+      auto mfmas_half = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[0][kk][i], xs2[0][kk][j], acc[i][j], 0, 0, 0);
+      };
+      static_assert(BK == 64, "half-tile pipelining: two 32-k halves per K-tile");
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
+        reads_half(0, buf);
+        if (kt > 0) mfmas_half(1);                       // second half of tile kt - 1 (read and retired in the last step)
+        if (kt == 0) fetch_epilogue_operands();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        reads_half(1, buf);
+        mfmas_half(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile kt's reads retired before the next hand-over
+        buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+      }
+      mfmas_half(1);
+    } else {
+      for (int kt = 0; kt < KT; kt += 2) {
+        body(std::integral_constant<int, 0>{}, kt);
+        if (kt == 0) fetch_epilogue_operands();
+        if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
+      }
+      if ((KT - 1) & 1) mfmas(std::integral_constant<int, 1>{});
+      else mfmas(std::integral_constant<int, 0>{});
     }
-    if ((KT - 1) & 1) mfmas(std::integral_constant<int, 1>{});
-    else mfmas(std::integral_constant<int, 0>{});
   } else
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = KT - 1 - kt;  // stages issued after tile kt
@@ -402,7 +457,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   }
 
   if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
-  float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // 1 KiB behind the ring (FUSE != 0 launches only)
+  float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // BM x 16 bytes behind the ring (FUSE != 0 launches only)
   if (FUSE == 1) {
     // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
     // M2 = sum_p M2_p + 64 sum_p (mean_p - mean)^2, rstd = rsqrt(M2 / K + eps)
@@ -422,7 +477,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
         m2 += pf_st[u][1] + cols * dm * dm;
       }
     m2 = add_xor2(add_xor1(m2));
-    if (sq == 0 && (NC == 256 || tid < 256)) {
+    if (sq == 0 && (NC == NSTATT || tid < NSTATT)) {
       fuse_lds[(tid >> 2) * 2] = mean;     // relative to the offset the row's xs was centred with (row_mean)
       fuse_lds[(tid >> 2) * 2 + 1] = rsqrtf(m2 / (float)a.K + a.ln_eps);
       // the producer behind this consumer centres with the row's CURRENT mean: one workgroup per row tile moves it along
@@ -654,7 +709,7 @@ inline bool pack_prefetch_on() {
   return true;
 }
 
-template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1>
+template <int BM, int BN, int EPI, int NSTAGE, int WGM = 2, int WGN = 2, int DBG = 0, int FUSE = 0, int NLOAD = 0, int DSTEP = 1, int DBUF = 1>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int BK = 64;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -672,11 +727,14 @@ int launch(GemmArgs& a, hipStream_t st) {
   // prefetch workgroups ride along only where the main grid leaves room on the chip for them to start at once
   int pf_wgs = ((WGM * WGN == 4 || NLOAD > 0) && a.n_main <= 3 * 256) ? f5e_prefetch_wgs(&a.pf) : 0;
   a.pf_per_wg = 0;
-  constexpr int lds_probe = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
-  if (NLOAD > 0 && 2 * lds_probe > 160 * 1024 && pf_wgs > 0 && pack_prefetch_on()) {
-    // one workgroup per CU (LDS): the prefetch goes to the CUs the main grid leaves idle, one packed workgroup each
+  constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? BM * 16 : 0);
+  if (NLOAD > 0 && 2 * lds > 160 * 1024 && pf_wgs > 0 && pack_prefetch_on()) {
+    // one workgroup per CU (LDS): the prefetch goes to the CUs the main grid leaves idle, one packed workgroup each; a
+    // grid that fills the chip hosts nothing (its prefetch workgroups could only run as a tail behind it)
     const int idle = f5e_cu_count() - a.n_main;
-    if (idle > 0 && pf_wgs > idle) {
+    if (idle <= 0) {
+      pf_wgs = 0;
+    } else if (pf_wgs > idle) {
       constexpr unsigned gran = 64u * (WGM * WGN + NLOAD) * 16u;   // one LDS-DMA of every thread of the workgroup
       const unsigned long long total = (unsigned long long)pf_wgs * F5E_PF_BYTES_PER_WG;
       a.pf_per_wg = (unsigned)(((total + idle - 1) / idle + gran - 1) / gran * gran);
@@ -685,11 +743,10 @@ int launch(GemmArgs& a, hipStream_t st) {
   }
   const int grid = a.n_main + pf_wgs;
   if (grid == a.n_main) a.pf = F5ePrefetch{};
-  constexpr int lds = NSTAGE * (BM + BN) * BK * 2 + (FUSE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static F5eDeviceOnce lds_once;  // > 64 KiB of dynamic LDS needs the opt-in attribute, per device (host-only call)
-  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP>), lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
+  if (lds > 65536) F5E_OPT_IN_LDS(lds_once, (gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, DBUF>), lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, NSTAGE, DBG, WGM, WGN, FUSE, NLOAD, DSTEP, DBUF>), dim3(grid), dim3(64 * (WGM * WGN + NLOAD)), lds, st, a);
   F5E_LAUNCH_CHECK("gemm_bf16");
   return F5E_OK;
 }
@@ -711,6 +768,14 @@ inline int role_var() {
   return -1;
 }
 
+// diagnostics build only: F5E_GEMM_BIG=0 -> no 128-row role-split tiles (the classic 64 x 64 kernels past M = 1024)
+inline bool big_tiles_on() {
+#ifdef F5E_TOOLS
+  if (const char* f = getenv("F5E_GEMM_BIG")) return atoi(f) != 0;
+#endif
+  return true;
+}
+
 template <int EPI>
 int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
@@ -729,6 +794,11 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
         if (a.K % 128 == 0 && role_var() != 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2>(a, st);
         return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1>(a, st);   // K % 128 != 0 (or F5E_GEMM_VAR=0 in the diagnostics build)
       }
+      // M in (1024, 2048] (C4's utterances): 128 x 64 tiles keep the grid to one round of role-split workgroups
+      if (role_split_on() && big_tiles_on() && blocks(128, 64) <= 256) {
+        if (a.K % 128 == 0) return launch<128, 64, EPI, 6, 4, 2, 0, 2, 4, 2>(a, st);
+        return launch<128, 64, EPI, 4, 4, 2, 0, 2, 4, 1>(a, st);
+      }
       if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 2>(a, st);
       return launch<64, 64, EPI, 3, 2, 2, 0, 2>(a, st);
     } else {
@@ -745,6 +815,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
           if ((wide & 1) && a.N % 192 == 0 && blocks(64, 192) <= 256) {
             return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1>(a, st);
           }
+          if (big_tiles_on() && a.N % 192 == 0 && blocks(128, 192) <= 256) return launch<128, 192, EPI, 3, 2, 6, 0, 1, 4, 1, 0>(a, st);
         } else {
           if ((wide & 2) && a.N % 128 == 0 && blocks(64, 128) <= 256) {
 #ifdef F5E_TOOLS
@@ -752,6 +823,12 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
 #endif
             // two K-tiles per hand-over: a fused consumer's K is a multiple of 256 (statistics parts % 4 == 0, set_consumer)
             if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2>(a, st);
+          }
+          if (big_tiles_on() && a.N % 128 == 0 && blocks(128, 128) <= 256) {
+#ifdef F5E_TOOLS
+            if (role_var() == 0) return launch<128, 128, EPI, 4, 2, 4, 0, 1, 4, 1, 1>(a, st);   // diagnostics build: two fragment sets (spills)
+#endif
+            return launch<128, 128, EPI, 4, 2, 4, 0, 1, 4, 1, 0>(a, st);
           }
         }
       }

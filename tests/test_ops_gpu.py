@@ -553,6 +553,9 @@ def test_qkv_rope_with_qk_rmsnorm(ops, hint):
     # the unfused reference launches below do take the 256 x 256 kernel) and a row count past the ping-pong crossover
     # (44 row tiles of 256), where a zero-initialised f5e_ln_fuse used to be refused
     (2, 469, 1024, 3072, 0.0, False, 9), (3, 150, 768, 1536, 0.7, True, 9), (24, 470, 1024, 256, 0.3, False, 0),
+    # M in (1024, 2048]: the 128-row role-split tiles (producer 128 x 64, consumer 128 x 128), a partial last row tile and
+    # a grid that fills all 256 CUs (M = 2048)
+    (2, 900, 1024, 3072, 0.3, True, 0), (2, 1024, 1024, 2048, 0.0, False, 0), (3, 500, 768, 1536, 0.7, True, 0),
     ])
 def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     """LayerNorm+modulate folded into the GEMMs either side of it (f5e_ln_fuse): adaln_pre / the gate+residual producer
@@ -626,7 +629,10 @@ def test_fused_adaln_chain(ops, S, N, D, NO, mean_shift, masked, hint):
     (3, 150, 12, 768),     # 8 x 12 wide tiles, D = 768 (the Small PPG model's widths)
     (1, 1, 4, 256),        # a single row: one row tile, K = 4 tiles (the ring's depth)
     (2, 131, 5, 512),      # odd rows per sequence, heads not a multiple of 4
-    (2, 640, 16, 1024),    # 20 x 16 = 320 wide tiles > 256: the classic 64 x 64 fused consumer
+    (2, 1300, 16, 1024),   # 41 x 16 wide tiles, 21 x 16 of 128 x 192: past one round either way -> the classic 64 x 64 consumer
+    (2, 640, 16, 1024),    # M = 1280: 10 x 16 tiles of 128 x 192 (12 consumer waves of 64 x 32, one fragment set)
+    (2, 1024, 16, 1024),   # M = 2048: 16 x 16 = 256 tiles, the whole chip
+    (4, 333, 12, 768),     # M = 1332, D = 768: 11 x 12 tiles, odd rows per sequence
 ])
 def test_fused_qkv_rope_consumer_role_split_and_classic(ops, S, N, H, K):
     """f5e_gemm_bf16_qkv_rope_ln (fused AdaLN consumer + RoPE + fragment-major q / k / v^T): against the fp32 reference
@@ -683,6 +689,9 @@ def test_fused_qkv_rope_consumer_role_split_and_classic(ops, S, N, H, K):
     (3, 150, 768, 1536, 0),    # the Small PPG model's FF1
     (2, 469, 1024, 2176, 0),   # 17 column tiles x 15 = 255: still one round
     (2, 469, 1024, 2304, 0),   # 18 x 15 = 270 > 256: the classic consumer
+    (2, 900, 1024, 2048, 0),   # M = 1800: 15 x 16 tiles of 128 x 128 (8 consumer waves of 64 x 32)
+    (3, 600, 768, 1536, 0),    # M = 1800, D = 768: 15 x 12 tiles
+    (2, 1100, 1024, 2048, 0),  # M = 2200: 18 x 16 > 256 -> the classic consumer
 ])
 def test_fused_gelu_consumer_role_split_and_classic(ops, S, N, D, NO, K_unused):
     """f5e_gemm_bf16_bias_ln with GELU(tanh) (FF1 behind the fused AdaLN, reference modules.py:637 + :348-349) on the wide

@@ -12,7 +12,8 @@ import torch
 def main():
     dev = "cuda"
     shapes = [("QKV", 3072, 1024), ("OUT", 1024, 1024), ("FF1", 2048, 1024), ("FF2", 1024, 2048)]
-    for M in (938, 60032):
+    Ms = [int(x) for x in sys.argv[1:]] or [938, 60032]   # optional: row counts on the command line
+    for M in Ms:
         for name, N, K in shapes:
             A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             Ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) for _ in range(22)]
