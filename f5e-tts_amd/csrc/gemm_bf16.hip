@@ -48,7 +48,7 @@ __device__ __forceinline__ void wait_stages(int nst) {
 
 // K-step 64: 128-byte LDS rows, two rows per 256-byte bank line, swizzle (row >> 1) & 7.  (Measured and dropped, DESIGN 4:
 // K-step 128, 5-8 stage rings, 8 waves on the 64x64 tile, intra-workgroup split-K for the one-workgroup-per-CU launches.)
-// DBG == 3: in-kernel timestamps for tools/gemm_trace.hip (never instantiated by the library).
+// DBG >= 3: in-kernel timestamps for tools/gemm_trace.hip (never instantiated by the library).
 // NLOAD > 0: ROLE SPLIT.  The workgroup gets NLOAD extra waves that do nothing but stage (every global_load_lds of the ring +
 // the counted vmcnt waits); the WGM x WGN consumer waves only ds_read and MFMA.  Why: the CU's texture-address path takes
 // ~18 cycles per 1 KiB LDS-DMA instruction (tools/l2_probe.hip: 57 B/clk per CU from L2, whatever the number of waves), so a
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   const int stid = NLOAD ? tid - NC : tid;               // index among the staging threads (loaders: 0 .. NT - 1)
   const int swave = NLOAD ? wave - NCW : wave;
   unsigned long long* trc = nullptr;
-  if constexpr (DBG == 3) {
+  if constexpr (DBG >= 3) {
     trc = a.trace + (size_t)blockIdx.x * 48;
     if (tid == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[1] = __builtin_amdgcn_s_memtime(); }
   }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       // tells us they are done reading the DSTEP tiles before), refill those buffers with tiles kt + NPRO ...  Same RAW / WAR
       // argument as the classic ring, per step of DSTEP tiles.
       int nbuf_l = NPRO % NSTAGE;
-      if constexpr (DBG == 3) { if (stid == 0) trc[47] = __builtin_amdgcn_s_memtime(); }
+      if constexpr (DBG >= 3) { if (stid == 0) trc[47] = __builtin_amdgcn_s_memtime(); }
       for (int kt = 0; kt < KT; kt += DSTEP) {
         // issued so far: tiles [0, min(KT, kt + NPRO)); all but the ones younger than this step's tiles must have landed:
         // min(tiles behind this step, NSTAGE - 2 DSTEP) may stay in flight
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   // vector loads between the prologue's LDS-DMAs and the first counted wait (run by `make check`).  `volatile` is no
   // way to pin them: hipcc turns volatile loads into flat_load sc0 sc1 + s_waitcnt vmcnt(0) each.
   asm volatile("" ::: "memory");
-  if constexpr (DBG == 3) { if (tid == 0) trc[46] = __builtin_amdgcn_s_memtime(); }
+  if constexpr (DBG >= 3) { if (tid == 0) trc[46] = __builtin_amdgcn_s_memtime(); }
   constexpr bool PREF = (TM * TN <= 4);
   // fused AdaLN: 64-row tiles of 32 x 32 wave sub-tiles (row statistics: 4 threads per row = the first 256 threads); the
   // producer is 64 x 64, a role-split consumer may be wider (64 x 128 / 64 x 192: the A panel is staged once per K-step)
@@ -239,9 +239,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   static_assert(FUSE != 2 || EPI == EPI_GATE_RES, "the AdaLN producer is the gate+residual epilogue");
   constexpr int NPC = NLOAD ? 0 : (FUSE == 1 ? 2 * TN + 4 : (FUSE == 2 ? 3 * TM * TN : ((PREF && EPI == EPI_GATE_RES) ? 2 * TM * TN : 0)));
   static_assert((NSTAGE - 2) * LPT + NPC <= 63, "vmcnt is a 6-bit counter");
-  f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? TM : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
+  // role split: one gate row (host check), so gate and next-norm scale depend on the column only -- TN loads, not TM x TN
+  // (the epilogue operands queue on the same address path as the loaders' DMAs: every load less is ~18 cycles per wave)
+  constexpr bool COLG = NLOAD > 0;
+  f32x4 pf_bias[PREF ? TN : 1], pf_gate[PREF ? TN : 1][PREF ? (COLG ? 1 : TM) : 1], pf_x[PREF ? TN : 1][PREF ? TM : 1];
   f32x4 pf_c[FUSE == 1 ? TN : 1], pf_d[FUSE == 1 ? TN : 1];
-  f32x4 pf_ns[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
+  f32x4 pf_ns[FUSE == 2 ? TN : 1][FUSE == 2 ? (COLG ? 1 : TM) : 1];
   f32x2 pf_st[FUSE == 1 ? 4 : 1];
   bool pf_live[PREF ? TM : 1];
   int pf_len[PREF ? TM : 1];
@@ -261,10 +264,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
             const int nc = min(n0 + wn0 + i * 16 + fq * 4, a.N - 4);
-            const size_t goff = eoff + (a.gate_rows == 1 ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
-            pf_gate[i][j] = ldv4(a.gate + goff);                       // counted
-            pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);      // counted
-            if (FUSE == 2) pf_ns[i][j] = ldv4(a.next_scale + goff);    // counted
+            const size_t goff = eoff + ((COLG || a.gate_rows == 1) ? 0 : (size_t)(seq % a.gate_rows) * a.gate_stride) + nc;
+            if (!COLG || j == 0) pf_gate[i][COLG ? 0 : j] = ldv4(a.gate + goff);                     // counted
+            pf_x[i][j] = ldv4(a.resid + (size_t)mc * a.ldr + nc);                                   // counted
+            if (FUSE == 2 && (!COLG || j == 0)) pf_ns[i][COLG ? 0 : j] = ldv4(a.next_scale + goff);  // counted
           }
         }
       }
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   if (NLOAD == 0) fetch_epilogue_operands();
 
   int buf = 0, nbuf = NSTAGE - 1;
-  if constexpr (DBG == 3) { if (tid == 0) trc[2] = __builtin_amdgcn_s_memtime(); }
+  if constexpr (DBG >= 3) { if (tid == 0) trc[2] = __builtin_amdgcn_s_memtime(); }
   if constexpr (NLOAD > 0) {
     // ---- consumer waves of a role-split launch.  Step kt: pass the barrier that hands tile kt over, issue its fragment
     // reads into one register set, run the MFMAs of tile kt - 1 from the other set under those reads, and retire the reads
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       constexpr int P = decltype(pc)::value;
       // DSTEP == 2: KT is even (host check), so tile parity P == position inside the step
       if (DSTEP == 1 || P == 0) __builtin_amdgcn_s_barrier();
-      if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
+      if constexpr (DBG >= 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
       reads(pc, buf);
       if (kt > 0) mfmas(std::integral_constant<int, 1 - P>{});
       if (DSTEP == 1 || P == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the next hand-over
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       // then all multiply (pipe-bound), and the two phases add up.  Reads of tile kt are retired before the barrier of
       // tile kt + 1 (the last wait of the step), behind which the loader refills tile kt - 1's ... kt's buffers in turn.
       auto reads_half = [&](int kk, int b) {
+        if constexpr (DBG == 5) return;
         const char* As = ring + b * STAGE;
         const char* Ws = As + A_BYTES;
         const int c = kk * 4 + fq;
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
         }
       };
       auto mfmas_half = [&](int kk) {
+        if constexpr (DBG == 4 || DBG == 5) return;   // tools/gemm_trace.hip ablations: 4 = no MFMAs, 5 = no fragment reads either
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       static_assert(BK == 64, "half-tile pipelining: two 32-k halves per K-tile");
       for (int kt = 0; kt < KT; ++kt) {
         __builtin_amdgcn_s_barrier();
-        if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
+        if constexpr (DBG >= 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
         reads_half(0, buf);
         if (kt > 0) mfmas_half(1);                       // second half of tile kt - 1 (read and retired in the last step)
         if (kt == 0) fetch_epilogue_operands();
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
     if (NPC > 0 && kt <= NSTAGE - 2) wait_stages<LPT, NPC>(nst);
     else wait_stages<LPT, 0>(nst);
     __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; everyone is done reading tile kt-1's buffer
-    if constexpr (DBG == 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (DBG >= 3) { if (tid == 0 && kt < 36) trc[4 + kt] = __builtin_amdgcn_s_memtime(); }
     // Order inside a K-step: the tile's fragment reads FIRST, then the LDS-DMAs of tile kt + NSTAGE - 1, then the MFMAs.
     // A DMA instruction costs the wave 100-185 cycles of issue while the CU's address path is busy (all waves of the CU
     // stage right behind the same barrier); issued ahead of the ds_reads -- the order of rounds 1-2 -- that stall delayed
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
     nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
 
-  if constexpr (DBG == 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
+  if constexpr (DBG >= 3) { if (tid == 0) trc[3] = __builtin_amdgcn_s_memtime(); }
   float* fuse_lds = (float*)(smem + NSTAGE * STAGE);  // BM x 16 bytes behind the ring (FUSE != 0 launches only)
   if (FUSE == 1) {
     // Chan's parallel variance over the 64-column partials, fixed order: mean = avg(mean_p),
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       if (tile_n == 0 && m0 + (tid >> 2) < a.M) a.row_mean[m0 + (tid >> 2)] += mean;
     }
     __syncthreads();
-    if constexpr (DBG == 3) { if (tid == 0) trc[42] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (DBG >= 3) { if (tid == 0) trc[42] = __builtin_amdgcn_s_memtime(); }
   }
   f32x4 xn[FUSE == 2 ? TN : 1][FUSE == 2 ? TM : 1];
   if (PREF && EPI == EPI_GATE_RES) {
@@ -568,12 +573,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
         *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
       } else if (EPI == EPI_GATE_RES && PREF) {
         if (pf_live[j]) {  // pf_x / pf_gate were fetched from clamped addresses: valid whenever m < M and n < N
-          const f32x4 x_new = pf_x[i][j] + pf_gate[i][j] * v;
+          const f32x4 x_new = pf_x[i][j] + pf_gate[i][COLG ? 0 : j] * v;
           *(f32x4*)(a.resid + (size_t)m * a.ldr + n) = x_new;
           if (FUSE == 2) xn[i][j] = x_new;
         }
         if (FUSE == 2) {
-          const f32x4 y = (xn[i][j] - pf_rm[j]) * (1.0f + pf_ns[i][j]);
+          const f32x4 y = (xn[i][j] - pf_rm[j]) * (1.0f + pf_ns[i][COLG ? 0 : j]);
           *(bf16x4*)(a.xs_out + (size_t)m * a.ld_xs + n) = f2bf4(y[0], y[1], y[2], y[3]);
         }
       } else if (EPI == EPI_GATE_RES) {
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       }
     }
   }
-  if constexpr (DBG == 3) { if (tid == 0) trc[43] = __builtin_amdgcn_s_memtime(); }
+  if constexpr (DBG >= 3) { if (tid == 0) trc[43] = __builtin_amdgcn_s_memtime(); }
   if (FUSE == 2) {
     // (mean, M2) of x_new over this wave's 32 columns, then the two waves of a row pair up through LDS
 #pragma unroll
@@ -642,10 +647,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       }
     }
     // LDS hand-off only: do not drain vmcnt here, the x / xs stores above stay in flight behind the barrier
-    if constexpr (DBG == 3) { if (tid == 0) trc[44] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (DBG >= 3) { if (tid == 0) trc[44] = __builtin_amdgcn_s_memtime(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (DBG == 3) { if (tid == 0) trc[45] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (DBG >= 3) { if (tid == 0) trc[45] = __builtin_amdgcn_s_memtime(); }
     if (tid < BM && m0 + tid < a.M) {
       const float ma = fuse_lds[tid * 4], qa = fuse_lds[tid * 4 + 1], mb = fuse_lds[tid * 4 + 2], qb = fuse_lds[tid * 4 + 3];
       const float dm = ma - mb;
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
       dst[1] = (qa + qb) + (0.25f * (float)BN) * dm * dm;  // delta^2 na nb / (na + nb), na = nb = BN / 2
     }
   }
-  if constexpr (DBG == 3) {
+  if constexpr (DBG >= 3) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) { trc[40] = __builtin_amdgcn_s_memtime(); trc[41] = __builtin_amdgcn_s_memrealtime(); }
   }
@@ -788,14 +793,14 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
       F5E_REQUIRE(a.stats_out && !a.ln_stats, "gemm_bf16: the gate+residual epilogue is the AdaLN producer");
       // one-round grids (out-projection / FF2 at batch 1: 240 workgroups on 256 CUs): role split, 4 loader + 4 consumer
       // waves, 4-stage ring -- see the NLOAD note at the kernel
-      if (role_split_on() && blocks(64, 64) <= 256) {
+      if (role_split_on() && a.gate_rows == 1 && blocks(64, 64) <= 256) {
         // two K-tiles per hand-over barrier on a ring of six (in situ at C2, ms per pass: classic ring 41.4; 4 stages, one tile
         // per barrier 40.9; this 40.7; 8-tile ring 41.2; 6 stages, one tile per barrier 41.8)
         if (a.K % 128 == 0 && role_var() != 0) return launch<64, 64, EPI, 6, 2, 2, 0, 2, 4, 2>(a, st);
         return launch<64, 64, EPI, 4, 2, 2, 0, 2, 4, 1>(a, st);   // K % 128 != 0 (or F5E_GEMM_VAR=0 in the diagnostics build)
       }
       // M in (1024, 2048] (C4's utterances): 128 x 64 tiles keep the grid to one round of role-split workgroups
-      if (role_split_on() && big_tiles_on() && blocks(128, 64) <= 256) {
+      if (role_split_on() && a.gate_rows == 1 && big_tiles_on() && blocks(128, 64) <= 256) {
         if (a.K % 128 == 0) return launch<128, 64, EPI, 6, 4, 2, 0, 2, 4, 2>(a, st);
         return launch<128, 64, EPI, 4, 4, 2, 0, 2, 4, 1>(a, st);
       }
@@ -815,6 +820,8 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
           if ((wide & 1) && a.N % 192 == 0 && blocks(64, 192) <= 256) {
             return launch<64, 192, EPI, 4, 2, 6, 0, 1, 4, 1>(a, st);
           }
+          // ring of 3 x 40 KiB (a 4th stage, with the statistics scratch aliased into the ring, changed nothing in the K loop
+          // and delayed the first tile: DESIGN 4)
           if (big_tiles_on() && a.N % 192 == 0 && blocks(128, 192) <= 256) return launch<128, 192, EPI, 3, 2, 6, 0, 1, 4, 1, 0>(a, st);
         } else {
           if ((wide & 2) && a.N % 128 == 0 && blocks(64, 128) <= 256) {
@@ -824,12 +831,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
             // two K-tiles per hand-over: a fused consumer's K is a multiple of 256 (statistics parts % 4 == 0, set_consumer)
             if (a.K % 128 == 0) return launch<64, 128, EPI, 6, 2, 4, 0, 1, 4, 2>(a, st);
           }
-          if (big_tiles_on() && a.N % 128 == 0 && blocks(128, 128) <= 256) {
-#ifdef F5E_TOOLS
-            if (role_var() == 0) return launch<128, 128, EPI, 4, 2, 4, 0, 1, 4, 1, 1>(a, st);   // diagnostics build: two fragment sets (spills)
-#endif
-            return launch<128, 128, EPI, 4, 2, 4, 0, 1, 4, 1, 0>(a, st);
-          }
+          if (big_tiles_on() && a.N % 128 == 0 && blocks(128, 128) <= 256) return launch<128, 128, EPI, 4, 2, 4, 0, 1, 4, 1, 0>(a, st);
         }
       }
       return launch<64, 64, EPI, 3, 2, 2, 0, 1>(a, st);
@@ -853,7 +855,7 @@ int dispatch(GemmArgs& a, hipStream_t st, int tile_hint) {
   if (sel == 1) return launch<128, 128, EPI, 2, 4, 2>(a, st);
   if (sel == 2) return launch<128, 64, EPI, 3>(a, st);
   if constexpr (EPI == EPI_GATE_RES) {
-    if (role_split_on() && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 0, 4>(a, st);
+    if (role_split_on() && a.gate_rows == 1 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4, 2, 2, 0, 0, 4>(a, st);
   }
   if (a.K >= 2048 && blocks(64, 64) <= 256) return launch<64, 64, EPI, 4>(a, st);
   return launch<64, 64, EPI, 3>(a, st);

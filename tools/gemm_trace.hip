@@ -1,4 +1,4 @@
-// Per-workgroup timeline of the bf16 GEMM kernel (diagnostic build, DBG == 3 stamps) inside a chain of dependent
+// Per-workgroup timeline of the bf16 GEMM kernel (diagnostic build, DBG >= 3 stamps) inside a chain of dependent
 // launches replayed from a hipGraph.  Answers: where do the microseconds of a small-M launch go (launch gap, start
 // ramp, first tile, K loop, epilogue)?    usage: gemm_trace.bin <variant> <M> <N> <K> <epi: 0 bf16, 1 gelu, 2 gate_res, 3 qkv+rope (2 sequences)>
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_trace.hip f5e-tts_amd/csrc/gemm_bf16_pp.hip -o tools/gemm_trace.bin
@@ -76,6 +76,24 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
     case 83:
       if constexpr (EPI != EPI_GATE_RES) { *bm = 64; *bn = 128; return launch<64, 128, EPI, 6, 2, 4, 3, 1, 4, 2>(a, st); }
       return -1;
+    // 128-row role-split tiles (M in (1024, 2048]): 90 the fused producer / consumers as dispatched, 93 the producer without
+    // the AdaLN fusion, 94 the 128 x 128 consumer with two full fragment sets
+    case 90:
+      if constexpr (EPI == EPI_GATE_RES) { *bm = 128; *bn = 64; return launch<128, 64, EPI, 6, 4, 2, 3, 2, 4, 2>(a, st); }
+      else if constexpr (EPI == EPI_QKV_ROPE) { *bm = 128; *bn = 192; return launch<128, 192, EPI, 3, 2, 6, 3, 1, 4, 1, 0>(a, st); }
+      else { *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 4, 3, 1, 4, 1, 0>(a, st); }
+    // 128-row tiles without the AdaLN fusion: fat consumer waves (64 x 64) vs 64 x 32 ones
+    case 96: *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 2, 3, 0, 4, 1, 1>(a, st);   // 4 consumers, two fragment sets
+    case 97: *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 2, 3, 0, 4, 1, 0>(a, st);   // 4 consumers, half-tile pipelined
+    case 98: *bm = 128; *bn = 192; return launch<128, 192, EPI, 4, 2, 3, 3, 0, 4, 1, 0>(a, st);   // 6 consumers of 64 x 64
+    case 100: *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 4, 3, 0, 4, 1, 0>(a, st);  // 8 consumers of 64 x 32
+    case 101: *bm = 128; *bn = 192; return launch<128, 192, EPI, 4, 2, 6, 3, 0, 4, 1, 0>(a, st);  // 12 consumers of 64 x 32
+    case 102: *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 4, 4, 0, 4, 1, 0>(a, st);  // 100 without MFMAs
+    case 103: *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 4, 5, 0, 4, 1, 0>(a, st);  // 100 without reads and MFMAs
+    case 93: *bm = 128; *bn = 64; return launch<128, 64, EPI, 6, 4, 2, 3, 0, 4, 2>(a, st);
+    case 94:
+      if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) { *bm = 128; *bn = 128; return launch<128, 128, EPI, 4, 2, 4, 3, 1, 4, 1, 1>(a, st); }
+      return -1;
     case 42:  // fused AdaLN, 4 loaders, 4 stages (what the dispatcher launches for the one-round producers)
       *bm = 64; *bn = 64;
       if constexpr (EPI == EPI_GATE_RES) return launch<64, 64, EPI, 4, 2, 2, 3, 2, 4>(a, st);
@@ -94,6 +112,11 @@ static int run_variant(int v, GemmArgs& a, hipStream_t st, int* bm, int* bn) {
       else return launch<64, 64, EPI, 3, 2, 2, 3, 1>(a, st);
   }
   return -1;
+}
+
+static bool is_fused(int variant) {
+  return variant == 10 || (variant >= 40 && variant <= 42) || (variant >= 73 && variant <= 76) || variant == 81 || variant == 83 ||
+         variant == 90 || variant == 94;
 }
 
 static double med(std::vector<double> v) {
@@ -154,7 +177,7 @@ int main(int argc, char** argv) {
     a.resid = resid; a.ldr = N; a.gate = gate; a.gate_stride = 0; a.gate_rows = 1; a.rows_per_seq = rps;
     if (epi == 3) { a.q = qb; a.k = kb; a.vt = vtb; a.n_pad = n_pad; a.heads = heads; a.rope_heads = heads; a.cos_sin = cs; }
     a.trace = trace + (size_t)l * max_grid * 48;
-    if (variant == 10 || (variant >= 40 && variant <= 42) || (variant >= 73 && variant <= 76) || variant == 81 || variant == 83) {
+    if (is_fused(variant)) {
       a.row_mean = row_mean;
       if (epi == 2) { a.xs_out = out; a.ld_xs = N; a.next_scale = gate; a.stats_out = stats; }
       else { a.ln_stats = stats; a.ln_parts = K / 64; a.ln_c = cd; a.ln_d = cd + N; a.cd_stride = 2 * N; a.cd_rows = 1;
@@ -227,7 +250,7 @@ int main(int argc, char** argv) {
     }
     printf("\n");
   }
-  if (variant == 10 || (variant >= 40 && variant <= 42) || (variant >= 73 && variant <= 76) || variant == 81 || variant == 83) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
+  if (is_fused(variant)) {  // fused AdaLN epilogue split (cycles after the K loop): slots 42..45, see gemm_bf16.hip
     std::vector<double> a42, a43, a44, a45, a40;
     const int l = L - 1;
     for (int w = 0; w < grid; ++w) {
