@@ -77,7 +77,8 @@ struct F5ePrefetch {
   const void* ptr[2];
   unsigned bytes[2];
 };
-// Granule: 32 KiB per workgroup (256 threads x 8 loads x 16 B).  The prefetch workgroups share their CUs' address path with
+// Granule (launches whose workgroups share a CU: attention, the classic GEMM kernels): 32 KiB per workgroup (256 threads x 8
+// loads x 16 B); the role-split GEMMs, one workgroup per CU, pack theirs instead (f5e_prefetch_run_packed below).  The prefetch workgroups share their CUs' address path with
 // the host launch's own LDS-DMAs, so FEWER, LONGER ones hurt the host (sweep at C2, ms per pass on one box: 256 KiB 48.3,
 // 128 KiB 45.4, 64 KiB -- rounds 2-3 -- 43.4, 32 KiB 41.4, 16 KiB 41.6, 8 KiB 41.7, 4 KiB 42.0; prefetch off 45.7).
 constexpr int F5E_PF_BYTES_PER_WG = 32 * 1024;

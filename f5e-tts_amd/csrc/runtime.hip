@@ -224,9 +224,12 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
     // Infinity-Cache prefetch (f5e_common.h): every GEMM / attention launch of a block drags the weights of the launch after
     // next into the memory-side cache with a few grid-tail workgroups, so the batch-1 GEMMs stop waiting for HBM.
     const bool pfon = p->mall_prefetch != 0;
-    // Who hosts what: QKV -> w_out, attention (not bound by the memory pipe: hosts for free) -> w_ff1, OUT -> w_ff2, FF2 (one
-    // workgroup per CU: room for the extra ones) -> the next block's w_qkv.  Measured at C2, ms per pass: off 48.35; FF1
-    // hosting the next w_qkv instead of FF2 47.45; this scheme 46.41; attention hosting both FF weights 46.95.
+    // Who hosts what: QKV -> w_out, attention (four-wave workgroups without an LDS ring: the extra ones start beside them) ->
+    // w_ff1, OUT -> w_ff2, FF2 -> the next block's w_qkv.  Measured at C2, ms per pass, round 2: off 48.35; FF1 hosting the
+    // next w_qkv instead of FF2 47.45; this scheme 46.41; attention hosting both FF weights 46.95.  Round 4: the role-split
+    // GEMMs pack their share onto the CUs their one-round grid leaves idle (gemm_bf16.hip launch()), after which five other
+    // assignments of the four weights to the five launches measure within 0.9 % of this one (the diagnostics build
+    // keeps them behind F5E_PF_SCHEME).
     const unsigned b_out = (unsigned)((size_t)D * inner * 2), b_ff = (unsigned)((size_t)p->FF * D * 2);
     const unsigned b_qkv = (unsigned)((size_t)3 * inner * D * 2);
     for (int l = 0; l < p->L; ++l) {

@@ -57,10 +57,14 @@ def draw():
         G = c(1, 2, 4, 16)
         return T.test_convpos, (r(1, 3), r(1, 500), G * c(16, 32, 48, 64), G)
     k2 = rng.random()
-    if k2 < 0.3:
+    if k2 < 0.2:
         hint = c(0, 9)
-        N = r(20, 330)
+        N = r(20, 330) if rng.random() < 0.5 else r(331, 1000)   # up to 3000 rows: the 64- and 128-row role-split tiles, the classic ones
         return T.test_fused_adaln_chain, (r(1, 3), N, c(256, 512, 768, 1024), 4 * r(8, 400), c(0.0, 0.3, 0.7), N >= 30 and c(False, True), hint)
+    if k2 < 0.3:
+        if rng.random() < 0.5:
+            return T.test_fused_qkv_rope_consumer_role_split_and_classic, (r(1, 4), r(1, 700), r(1, 16), c(256, 512, 768, 1024))
+        return T.test_fused_gelu_consumer_role_split_and_classic, (r(1, 4), r(1, 700), c(256, 512, 768, 1024), c(4 * r(8, 600), 128 * r(1, 20)), 0)
     if k2 < 0.5:
         return T.test_grn, (r(1, 3), r(1, 400), c(64, 66, 192, 512, 1024))
     if k2 < 0.7:
