@@ -144,30 +144,35 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void gemm_bf16_kernel(Gem
   constexpr int A_IT = BM * CPR / NT;
   constexpr int W_IT = BN * CPR / NT;
   static_assert(A_IT >= 1 && W_IT >= 1 && A_IT * NT == BM * CPR && W_IT * NT == BN * CPR, "tile / thread-count mismatch");
-  const bf16* a_src[A_IT];
-  const bf16* w_src[W_IT];
+  // Source addresses as a wave-UNIFORM 64-bit base (the tile's first row, advanced by the K-tile: scalar registers, scalar
+  // adds) + a loop-invariant 32-bit byte offset per lane: the LDS-DMAs take the `saddr` form (glds16_s) and the staging of a
+  // K-tile needs no vector ALU instruction -- per-lane 64-bit pointers cost one v_lshl_add_u64 per DMA per K-tile on a SIMD
+  // whose vector issue the consumers' MFMAs hold half of the time.  Worth 0.5 % of a C2 pass.
+  unsigned a_off[A_IT], w_off[W_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
     const int i = (stid & (NT - 1)) + NT * j;
     const int row = i / CPR, c = (i % CPR) ^ swz(row);
-    const int gr = min(m0 + row, a.M - 1);
-    a_src[j] = a.A + (size_t)gr * a.lda + c * 8;
+    a_off[j] = (unsigned)(min(m0 + row, a.M - 1) - m0) * (unsigned)(a.lda * 2) + (unsigned)c * 16u;   // m0 < M: never negative
   }
 #pragma unroll
   for (int j = 0; j < W_IT; ++j) {
     const int i = (stid & (NT - 1)) + NT * j;
     const int row = i / CPR, c = (i % CPR) ^ swz(row);
-    const int gr = min(n0 + row, a.N - 1);
-    w_src[j] = a.W + (size_t)gr * a.ldw + c * 8;
+    w_off[j] = (unsigned)(min(n0 + row, a.N - 1) - n0) * (unsigned)(a.ldw * 2) + (unsigned)c * 16u;
   }
+  const char* const a_base = (const char*)(a.A + (size_t)m0 * a.lda);   // uniform
+  const char* const w_base = (const char*)(a.W + (size_t)n0 * a.ldw);
   const int KT = a.K / BK;
   char* const ring = smem;
   auto stage = [&](int buf, int kt) {
     char* base = ring + buf * STAGE;
+    const char* ak = a_base + (size_t)kt * (BK * 2);
+    const char* wk = w_base + (size_t)kt * (BK * 2);
 #pragma unroll
-    for (int j = 0; j < A_IT; ++j) glds16(a_src[j] + kt * BK, base + (swave * 64 + NT * j) * 16);
+    for (int j = 0; j < A_IT; ++j) glds16_s(ak, a_off[j], base + (swave * 64 + NT * j) * 16);
 #pragma unroll
-    for (int j = 0; j < W_IT; ++j) glds16(w_src[j] + kt * BK, base + A_BYTES + (swave * 64 + NT * j) * 16);
+    for (int j = 0; j < W_IT; ++j) glds16_s(wk, w_off[j], base + A_BYTES + (swave * 64 + NT * j) * 16);
   };
 
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;

@@ -69,6 +69,18 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) {
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_GATE_RES = 2, EPI_QKV_ROPE = 3, EPI_F32 = 4 };
 
+// LDS-DMA with the `saddr` address form: 64-bit wave-uniform base in scalar registers + 32-bit byte offset per lane.  Written
+// as inline assembly because the compiler folds (uniform base + lane offset) into per-lane 64-bit pointers again (one
+// v_lshl_add_u64 per DMA per K-tile).  M0 = LDS byte address of the wave's first lane (the DMA adds lane * 16); one wait state
+// between the write of M0 and the DMA.  Counted vmcnt waits see these like the builtin's loads (tools/check_vmcnt.py reads the ISA).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // "m0 is reserved": the clobber is what we mean -- the DMA builtins set M0 themselves
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, void* lds) {
+  const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
