@@ -243,18 +243,26 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
       F5ePrefetch pf_attn{{w.w_ff1, nullptr}, {b_ff, 0}};
       F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
       F5ePrefetch pf_nx = pf_next, pf_ff1{};
+      {
+        // Past one round of 64-row tiles (M > 1024 at D = 1024: C4's utterances) the launches are 2-3 x as long and the
+        // assignment that wins is another one: attention hosts both FF weights, FF2 the next block's w_qkv AND w_out, QKV and
+        // the out-projection nothing (C4 one utterance at a time, ms per utterance, arms alternated twice: 33.65 -> 33.33;
+        // at C2 the same assignment costs 4 %: FF2's 16 packed workgroups do not get 8.4 MB out in its 11 us).
+        int scheme = ((M + 63) / 64) * (D / 64) <= f5e_cu_count() ? 0 : 3;
 #ifdef F5E_TOOLS
-      {  // diagnostics build only: hosting schemes for A/B (F5E_PF_SCHEME)
-        static const int scheme = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : 0;
+        static const int scheme_env = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : -1;   // diagnostics build: A/B
+        if (scheme_env >= 0) scheme = scheme_env;
+#endif
         const void* wout_next = l + 1 < p->L ? (const void*)p->blocks[l + 1].w_out : nullptr;
         if (scheme == 1 || scheme == 3) {   // attention hosts both FF weights, the out-projection nothing
           pf_attn = F5ePrefetch{{w.w_ff1, w.w_ff2}, {b_ff, b_ff}};
           pf_out = F5ePrefetch{};
         }
-        if (scheme == 2 || scheme == 3) {   // FF2 hosts the next block's w_qkv AND w_out, QKV nothing
+        if (scheme == 2 || scheme == 3) {   // FF2 hosts the next block's w_qkv AND w_out, QKV nothing (block 0: its own w_out)
           pf_nx = F5ePrefetch{{pf_next.ptr[0], wout_next}, {pf_next.bytes[0], wout_next ? b_out : 0}};
           if (l > 0) pf_qkv = F5ePrefetch{};
         }
+#ifdef F5E_TOOLS
         if (scheme == 5 || scheme == 6) {   // the GEMMs host everything, attention nothing
           pf_qkv = F5ePrefetch{{w.w_out, w.w_ff1}, {b_out, b_ff}};
           pf_attn = F5ePrefetch{};
@@ -269,8 +277,8 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
           pf_attn = F5ePrefetch{{w.w_ff1, pf_next.ptr[0]}, {b_ff, pf_next.bytes[0]}};
           pf_nx = F5ePrefetch{};
         }
-      }
 #endif
+      }
       cons.c = cdl; cons.d = cdl + 3 * inner;
       F5E_TIMED(F5E_OP_QKV, f5e_gemm_bf16_qkv_rope_pf(st, p->hn, D, w.w_qkv, D, nullptr, p->q, p->k, p->vt, p->n_pad, p->H,
                                         p->rope_heads, p->rope_cs, nullptr, nullptr, p->N, M, D, 0, &cons, pfon ? &pf_qkv : nullptr));
