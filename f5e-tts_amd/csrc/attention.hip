@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NSPLIT * 64, 2) void attn_fwd_kernel(AttnArgs a) { 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
-  if constexpr (NSPLIT >= 2) if ((int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
+  if ((int)blockIdx.x >= a.n_main) {   // grid-tail workgroups: Infinity-Cache prefetch only (f5e_common.h)
     f5e_prefetch_run<NSPLIT * 64>(a.pf, (int)blockIdx.x - a.n_main, threadIdx.x, red);
     return;
   }
@@ -568,13 +568,22 @@ int f5e_flash_attn_pf(hipStream_t st, const void* q, const void* k, const void* 
     return F5E_OK;
   }
   if (splits <= 0) {
-    // aim for >= ~2k waves (2 per SIMD on 256 CUs) without splitting sequences that have few key tiles
+    // The 4-way split (256-VGPR waves, two workgroups per CU) while its grid is ONE round: up to 2 workgroups per CU; past
+    // that no split at all.  Round 4, us per launch in a 22-launch graph, S x H = 32 (tools/attn_splits.py,
+    // profiles/r04_ai_attn_splits.txt): 512 q-tiles: 4 splits 7.8, none 8.2; 544: 10.6 / 8.5; 960 (N = 938): 16.4 / 13.1;
+    // 1408 (N = 1390): 28.3 / 27.1; two splits never ahead of both.  (Rounds 1-3 split four ways up to 1024 q-tiles and two
+    // ways up to 2048: tuned at C2's 480 and never re-measured at C4's 640-1400.)
     const int ktiles = (rows_per_seq + 63) / 64;
-    splits = grid >= 2048 ? 1 : (grid >= 1024 ? 2 : 4);
+    splits = grid > 2 * f5e_cu_count() ? 1 : 4;
     while (splits > 1 && splits > ktiles) splits >>= 1;
   }
   switch (splits) {
-    case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid), dim3(64), 0, st, a); break;
+    case 1: {
+      const int npf = f5e_prefetch_wgs(pf);
+      if (npf) a.pf = *pf;
+      hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(grid + npf), dim3(64), 0, st, a);
+      break;
+    }
     case 2: {
       const int npf = f5e_prefetch_wgs(pf);
       if (npf) a.pf = *pf;

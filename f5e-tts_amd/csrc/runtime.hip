@@ -244,11 +244,10 @@ int f5e_dit_forward(hipStream_t st, const f5e_dit_plan* p) {
       F5ePrefetch pf_out{{w.w_ff2, nullptr}, {b_ff, 0}};
       F5ePrefetch pf_nx = pf_next, pf_ff1{};
       {
-        // Past one round of 64-row tiles (M > 1024 at D = 1024: C4's utterances) the launches are 2-3 x as long and the
-        // assignment that wins is another one: attention hosts both FF weights, FF2 the next block's w_qkv AND w_out, QKV and
-        // the out-projection nothing (C4 one utterance at a time, ms per utterance, arms alternated twice: 33.65 -> 33.33;
-        // at C2 the same assignment costs 4 %: FF2's 16 packed workgroups do not get 8.4 MB out in its 11 us).
-        int scheme = ((M + 63) / 64) * (D / 64) <= f5e_cu_count() ? 0 : 3;
+        // One assignment at every M.  (For a while in round 4 launches past one round of 64-row tiles switched to scheme 3 --
+        // attention hosting both FF weights, FF2 the next w_qkv and w_out: C4 -0.8 % -- until the attention kernel stopped
+        // splitting K/V at those sizes: unsplit it pays 2.4 us for hosting 8.4 MB, and scheme 0 is ahead again)
+        int scheme = 0;
 #ifdef F5E_TOOLS
         static const int scheme_env = getenv("F5E_PF_SCHEME") ? atoi(getenv("F5E_PF_SCHEME")) : -1;   // diagnostics build: A/B
         if (scheme_env >= 0) scheme = scheme_env;

@@ -1,7 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04bp_prof -o b2 -- python3 $R/bench.py --batch 2 --no-cpu-baseline --no-c3 --no-roofline --streams 0 --c4-total 0 --steps 5 --warmup 2 > $R/gpurun_out/r04bp.json 2> $R/gpurun_out/r04bp.err || { tail -5 $R/gpurun_out/r04bp.err; exit 1; }
-cd $R
-f=$(find gpurun_out/r04bp_prof -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r04bp_kernel_stats_batch2.csv
-python3 tools/prof_ops.py trace gpurun_out/r04bp_prof C2 gpurun_out/r04bp_ops_trace_batch2.json
-find gpurun_out/r04bp_prof -type f -size +2M -delete
+cd $GRAFT_REPO_ROOT
+T="F5E_HIP_LIB=$GRAFT_REPO_ROOT/f5e-tts_amd/libf5e_hip_tools.so"
+bash tools/gpu_ab.sh r04bv --args "--workload C4 --steps 100 --streams 0" "$T F5E_PF_SCHEME=3" "$T F5E_PF_SCHEME=7" "$T F5E_PF_SCHEME=6" "$T F5E_PF_SCHEME=5" "$T F5E_PF_SCHEME=0" "$T F5E_PF_SCHEME=3" "$T F5E_PF_SCHEME=7" "$T F5E_PF_SCHEME=6" "$T F5E_PF_SCHEME=5" "$T F5E_PF_SCHEME=0" | grep "C2 " | awk '{print NR, $2, $4}'
+bash tools/gpu_ab.sh r04bw --args "--batch 2 --no-c3 --c4-total 0 --streams 0 --steps 10" "$T F5E_PF_SCHEME=3" "$T F5E_PF_SCHEME=7" "$T F5E_PF_SCHEME=6" | grep "C2 "
