@@ -181,7 +181,11 @@ def pack_qkv(ops, q, k, v, n_pad):
 @pytest.mark.parametrize("S,H,N,waves,masked", [(2, 16, 469, 0, False), (2, 4, 469, 4, True), (3, 2, 64, 2, True),
                                                 (1, 2, 130, 4, False), (2, 2, 33, 1, True), (1, 16, 1875, 0, False),
                                                 (2, 4, 469, -1, True), (1, 2, 130, -1, False), (3, 2, 64, -1, True),
-                                                (2, 2, 33, -1, True), (8, 16, 938, 0, True)])
+                                                (2, 2, 33, -1, True), (8, 16, 938, 0, True),
+                                                # round 4 split rule: 512 query tiles = the last 4-way split, 544 and C4's
+                                                # 640 / 960 / 1408 unsplit (auto), ragged lengths on both sides
+                                                (2, 16, 512, 0, True), (2, 16, 530, 0, True), (2, 16, 640, 0, False),
+                                                (2, 16, 938, 0, True), (2, 16, 1390, 0, False)])
 def test_flash_attn(ops, S, H, N, waves, masked):
     n_pad = (N + 63) // 64 * 64
     # q as f5e_gemm_bf16_qkv_rope hands it over: pre-multiplied by log2(e) / 8 before the bf16 rounding (f5e_abi.h)
