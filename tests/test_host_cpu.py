@@ -548,3 +548,25 @@ def test_library_exports_only_the_declared_c_abi():
                          capture_output=True, text=True, check=True).stdout
     exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
     assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))
+
+
+def test_prof_ops_derive_short_and_long_dispatches():
+    """tools/prof_ops.py derive(): on a long dispatch the GRBM quotient is a clock; on a short one (counter window longer than
+    the kernel's span) it must be nulled and the span-based lower bound of the matrix pipe's share reported instead."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("prof_ops", os.path.join(ROOT, "tools", "prof_ops.py"))
+    po = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(po)
+    long_row, short_row = {}, {}
+    # 400 us at 2.2 GHz: 880 000 cycles per XCD x 8; matrix pipe 40 % busy on 1024 SIMDs
+    c_long = {"GRBM_GUI_ACTIVE": 8 * 880_000.0, "SQ_VALU_MFMA_BUSY_CYCLES": 0.4 * 1024 * 880_000.0,
+              "SQ_WAVE_CYCLES": 1e9, "SQ_WAIT_ANY": 4e8}
+    po.derive(long_row, c_long, 400.0)
+    assert abs(long_row["eff_clock_ghz"] - 2.2) < 1e-3 and abs(long_row["mfma_busy"] - 0.4) < 1e-4
+    assert "mfma_busy_span_min" not in long_row and abs(long_row["wave_cycles_parked"] - 0.4) < 1e-4
+    # 12 us kernel whose counter window is 1.5 x its span at 2.4 GHz
+    win = 12.0e3 * 2.4 * 1.5
+    c_short = {"GRBM_GUI_ACTIVE": 8 * win, "SQ_VALU_MFMA_BUSY_CYCLES": 0.2 * 1024 * 12.0e3 * 2.4}
+    po.derive(short_row, c_short, 12.0)
+    assert short_row["eff_clock_ghz"] is None and abs(short_row["counter_window_over_span"] - 1.5) < 1e-2
+    assert abs(short_row["mfma_busy_span_min"] - 0.2) < 1e-4 and abs(short_row["mfma_busy"] - 0.2 / 1.5) < 1e-4
