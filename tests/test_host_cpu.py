@@ -570,3 +570,34 @@ def test_prof_ops_derive_short_and_long_dispatches():
     po.derive(short_row, c_short, 12.0)
     assert short_row["eff_clock_ghz"] is None and abs(short_row["counter_window_over_span"] - 1.5) < 1e-2
     assert abs(short_row["mfma_busy_span_min"] - 0.2) < 1e-4 and abs(short_row["mfma_busy"] - 0.2 / 1.5) < 1e-4
+
+
+def test_profile_summaries_are_read_back_only_on_matching_kernel_sources(tmp_path, monkeypatch):
+    """bench.py carries rocprofv3 / PMC summaries from profiles/ only when they were measured on the kernel sources that run
+    (tools/src_hash.py): a summary with another hash is refused with the reason; stale committed ones only warn here."""
+    import importlib.util
+    from tools.src_hash import csrc_sha256
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = csrc_sha256()
+    stale_names = [name for name in ("ops_trace_c2", "ops_trace_c3", "ops_pmc_c2", "ops_pmc_c3", "pmc_traffic_c2")
+                   if json.load(open(os.path.join(ROOT, "profiles", name + ".json"))).get("csrc_sha256") != h]
+    if stale_names:   # mid-round state (kernels changed, profile not re-taken yet): bench.py then emits nulls + the reason
+        import warnings
+        warnings.warn(f"profiles/{stale_names} were measured on other kernel sources: re-run tools/gpu_profile.sh")
+    ops_, note = bench.stamped_ops("ops_trace_c2")
+    if not stale_names:
+        assert ops_ is not None and set(ops_) >= {"QKV", "ATTN", "OUT", "FF1", "FF2"}
+    else:
+        assert ops_ is None and "mismatch" in note
+    # a summary stamped with another hash is refused, with the reason in the note
+    fake_root = tmp_path / "repo"
+    (fake_root / "profiles").mkdir(parents=True)
+    stale = dict(json.load(open(os.path.join(ROOT, "profiles", "ops_trace_c2.json"))), csrc_sha256="0" * 64)
+    (fake_root / "profiles" / "ops_trace_c2.json").write_text(json.dumps(stale))
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    ops2, note2 = bench.stamped_ops("ops_trace_c2")
+    assert ops2 is None and "mismatch" in note2
+    ops3, note3 = bench.stamped_ops("ops_trace_c9")
+    assert ops3 is None and "no profiles/" in note3
